@@ -1,0 +1,190 @@
+"""ctypes loader for the CPU oracle (oracle/libapd_oracle.so).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from audio_pattern_discovery_amd/.
+PARITY UNPINNED: see oracle/apd_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libapd_oracle.so")
+
+
+class OrcOp(C.Structure):
+    _fields_ = [("merge_i", C.c_uint32), ("merge_j", C.c_uint32), ("into", C.c_uint32),
+                ("distance", C.c_float), ("operation", C.c_uint32)]
+
+
+MERGE_NAMES = ("Sequence2Sequence", "Sequence2Cluster", "Cluster2Sequence", "Cluster2Cluster")
+
+
+def build():
+    src = os.path.join(_HERE, "apd_oracle.c")
+    if (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        build()
+    L = C.CDLL(_SO)
+    f32p, u64p, u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    L.orc_euclidean.restype = C.c_float
+    L.orc_euclidean.argtypes = [f32p, f32p, C.c_uint32]
+    L.orc_warping_band.restype = C.c_uint64
+    L.orc_warping_band.argtypes = [C.c_float, C.c_uint64]
+    L.orc_dtw_cells.restype = C.c_uint64
+    L.orc_dtw_cells.argtypes = [C.c_uint64] * 3
+    for name in ("orc_dtw_pair", "orc_dtw_pair_hashmap"):
+        fn = getattr(L, name)
+        fn.restype = C.c_float
+        fn.argtypes = [f32p, C.c_uint64, f32p, C.c_uint64, C.c_uint32, C.c_uint64,
+                       C.c_float, C.c_float, C.c_float]
+    L.orc_align_all.restype = C.c_int
+    L.orc_align_all.argtypes = [f32p, u64p, C.c_uint32, C.c_uint32, C.c_float, C.c_float,
+                                C.c_float, C.c_float, C.c_uint32, C.c_int, f32p]
+    L.orc_align_sample.restype = C.c_int
+    L.orc_align_sample.argtypes = [f32p, u64p, C.c_uint32, C.c_uint32, C.c_float, C.c_float,
+                                   C.c_float, C.c_float, u32p, u32p, C.c_uint64, C.c_uint32,
+                                   C.c_int, f32p, u64p]
+    L.orc_percentile.restype = C.c_int
+    L.orc_percentile.argtypes = [f32p, C.c_uint64, C.c_float, f32p]
+    L.orc_clustering.restype = C.c_int
+    L.orc_clustering.argtypes = [f32p, C.c_uint32, C.c_float, C.POINTER(OrcOp), u32p, u32p, u32p, f32p]
+    L.orc_cluster_sets.restype = C.c_int
+    L.orc_cluster_sets.argtypes = [C.POINTER(OrcOp), C.c_uint32, u32p, C.c_uint32, C.c_uint32,
+                                   u32p, u32p, u32p]
+    L.orc_encode.restype = None
+    L.orc_encode.argtypes = [f32p, C.c_uint64, C.c_uint32, f32p, f32p, C.c_uint32, f32p]
+    L.orc_cepstrum.restype = C.c_uint64
+    L.orc_cepstrum.argtypes = [C.POINTER(C.c_int16), C.c_uint64, C.c_uint32, C.c_uint32,
+                               C.c_uint32, f32p, u32p]
+    _lib = L
+    return L
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def warping_band(pct, n_size):
+    return int(lib().orc_warping_band(float(pct), int(n_size)))
+
+
+def dtw_cells(n, m, band):
+    return int(lib().orc_dtw_cells(int(n), int(m), int(band)))
+
+
+def dtw_pair(x, y, band, ins=1.0, dele=1.0, match=1.0, hashmap=False):
+    """Alignment::new + construct_alignment + score (alignments.rs:107-180)."""
+    x, y = _f32(x), _f32(y)
+    dim = x.shape[1] if x.ndim == 2 else y.shape[1]
+    fn = lib().orc_dtw_pair_hashmap if hashmap else lib().orc_dtw_pair
+    return float(fn(_p(x, C.c_float), x.shape[0], _p(y, C.c_float), y.shape[0], dim, int(band),
+                    float(ins), float(dele), float(match)))
+
+
+def align_all(frames, offsets, band_pct, ins=1.0, dele=1.0, match=1.0, workers=4, hashmap=False):
+    """AlignmentWorkers::new + align_all (alignments.rs:17-67) -> (n, n) float32."""
+    frames = _f32(frames)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(offsets) - 1
+    out = np.empty((n, n), dtype=np.float32)
+    rc = lib().orc_align_all(_p(frames, C.c_float), _p(offsets, C.c_uint64), n, frames.shape[1],
+                             float(band_pct), float(ins), float(dele), float(match), int(workers),
+                             int(hashmap), _p(out, C.c_float))
+    if rc != 0:
+        raise ValueError("orc_align_all failed")
+    return out
+
+
+def align_sample(frames, offsets, pi, pj, band_pct, ins=1.0, dele=1.0, match=1.0, workers=1,
+                 hashmap=False):
+    frames = _f32(frames)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    pi = np.ascontiguousarray(pi, dtype=np.uint32)
+    pj = np.ascontiguousarray(pj, dtype=np.uint32)
+    out = np.empty(len(pi), dtype=np.float32)
+    cells = C.c_uint64(0)
+    rc = lib().orc_align_sample(_p(frames, C.c_float), _p(offsets, C.c_uint64), len(offsets) - 1,
+                                frames.shape[1], float(band_pct), float(ins), float(dele),
+                                float(match), _p(pi, C.c_uint32), _p(pj, C.c_uint32), len(pi),
+                                int(workers), int(hashmap), _p(out, C.c_float), C.byref(cells))
+    if rc != 0:
+        raise ValueError("orc_align_sample failed")
+    return out, int(cells.value)
+
+
+def percentile(x, perc):
+    x = _f32(x).ravel()
+    v = C.c_float(0)
+    if lib().orc_percentile(_p(x, C.c_float), x.size, float(perc), C.byref(v)) != 0:
+        raise IndexError("percentile index out of range (the reference panics here)")
+    return float(v.value)
+
+
+def clustering(dist, n, perc):
+    """AgglomerativeClustering::clustering (clustering.rs:81-110), literal.
+    Returns (ops list of dicts, sorted root ids, threshold)."""
+    dist = _f32(dist).ravel()
+    ops = (OrcOp * max(n, 1))()
+    roots = np.zeros(max(n, 1), dtype=np.uint32)
+    n_ops, n_roots, thr = C.c_uint32(0), C.c_uint32(0), C.c_float(0)
+    rc = lib().orc_clustering(_p(dist, C.c_float), n, float(perc), ops, C.byref(n_ops),
+                              _p(roots, C.c_uint32), C.byref(n_roots), C.byref(thr))
+    if rc != 0:
+        raise IndexError("clustering: percentile index out of range (the reference panics here)")
+    out = [dict(merge_i=o.merge_i, merge_j=o.merge_j, into=o.into, distance=o.distance,
+                operation=MERGE_NAMES[o.operation]) for o in ops[:n_ops.value]]
+    return out, [int(r) for r in roots[:n_roots.value]], float(thr.value)
+
+
+def cluster_sets(ops, roots, n):
+    arr = (OrcOp * max(len(ops), 1))()
+    for t, o in enumerate(ops):
+        arr[t].merge_i, arr[t].merge_j, arr[t].into = o["merge_i"], o["merge_j"], o["into"]
+        arr[t].distance = o.get("distance", 0.0)
+        arr[t].operation = MERGE_NAMES.index(o["operation"]) if "operation" in o else 0
+    r = np.ascontiguousarray(roots, dtype=np.uint32)
+    members = np.zeros(max(n + 2 * len(ops), 1), dtype=np.uint32)
+    set_off = np.zeros(len(roots) + 2, dtype=np.uint32)
+    n_sets = C.c_uint32(0)
+    lib().orc_cluster_sets(arr, len(ops), _p(r, C.c_uint32), len(roots), n, _p(members, C.c_uint32),
+                           _p(set_off, C.c_uint32), C.byref(n_sets))
+    return [members[set_off[s]:set_off[s + 1]].tolist() for s in range(n_sets.value)]
+
+
+def encode(x, w, b):
+    """AutoEncoder::predict per frame (neural.rs:55-71)."""
+    x, w, b = _f32(x), _f32(w), _f32(b).ravel()
+    out = np.empty((x.shape[0], w.shape[1]), dtype=np.float32)
+    lib().orc_encode(_p(x, C.c_float), x.shape[0], x.shape[1], _p(w, C.c_float), _p(b, C.c_float),
+                     w.shape[1], _p(out, C.c_float))
+    return out
+
+
+def cepstrum(samples, fft_size, fft_step, filter_size):
+    """Cepstrum frames of NDSequence::new (spectrogram.rs:31-80)."""
+    s = np.ascontiguousarray(samples, dtype=np.int16)
+    nb = C.c_uint32(0)
+    t = lib().orc_cepstrum(_p(s, C.c_int16), s.size, fft_size, fft_step, filter_size, None, C.byref(nb))
+    out = np.empty((t, nb.value), dtype=np.float32)
+    if t:
+        lib().orc_cepstrum(_p(s, C.c_int16), s.size, fft_size, fft_step, filter_size,
+                           _p(out, C.c_float), C.byref(nb))
+    return out

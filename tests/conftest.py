@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (oracle/libapd_oracle.so), built on demand.  Checker only."""
+    from oracle import binding
+    binding.build()
+    binding.lib()
+    return binding
+
+
+@pytest.fixture(scope="session")
+def apd():
+    """The product library through its C ABI (ctypes), no compute call made here."""
+    from audio_pattern_discovery_amd import _lib
+    return _lib
