@@ -1,0 +1,162 @@
+"""ctypes binding of libapd_hip.so -- the C ABI declared in include/apd.h.
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is no CPU
+fallback: a missing library raises ImportError-like errors here, a missing GPU makes
+``Context()`` raise ``ApdError(APD_ERR_NO_DEVICE)``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libapd_hip.so")
+
+APD_OK = 0
+APD_ERR_INVALID_ARG = -1
+APD_ERR_NO_DEVICE = -2
+APD_ERR_HIP = -3
+APD_ERR_OOM = -4
+APD_ERR_EMPTY_SEQUENCE = -5
+APD_ERR_BAND_TOO_WIDE = -6
+APD_ERR_INDEX = -7
+APD_ERR_UNSUPPORTED = -8
+
+
+class AlignConfig(C.Structure):
+    """apd_align_config: the Discovery fields the path reads (discovery.rs:17-20)."""
+    _fields_ = [("warping_band_percentage", C.c_float), ("insertion_penalty", C.c_float),
+                ("deletion_penalty", C.c_float), ("match_penalty", C.c_float)]
+
+
+class AlignmentParamsC(C.Structure):
+    """apd_alignment_params: AlignmentParams (alignments.rs:77-83)."""
+    _fields_ = [("warping_band", C.c_uint64), ("insertion_penalty", C.c_float),
+                ("deletion_penalty", C.c_float), ("match_penalty", C.c_float)]
+
+
+class ClusterOp(C.Structure):
+    """apd_cluster_op: ClusteringOperation (clustering.rs:19-25)."""
+    _fields_ = [("merge_i", C.c_uint32), ("merge_j", C.c_uint32), ("into", C.c_uint32),
+                ("distance", C.c_float), ("operation", C.c_uint32)]
+
+
+class ApdError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = "apd status %d" % status
+        try:
+            msg = "%s (%s)" % (lib().apd_status_string(status).decode(), status)
+        except Exception:
+            pass
+        super().__init__(msg + (": " + detail if detail else ""))
+
+
+# every symbol include/apd.h declares: (name, restype, argtypes)
+_f32p, _u64p, _u32p, _vp = C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_void_p
+SYMBOLS = [
+    ("apd_create", C.c_int, [C.c_int, C.POINTER(_vp)]),
+    ("apd_destroy", C.c_int, [_vp]),
+    ("apd_set_stream", C.c_int, [_vp, _vp]),
+    ("apd_synchronize", C.c_int, [_vp]),
+    ("apd_status_string", C.c_char_p, [C.c_int]),
+    ("apd_last_error", C.c_char_p, [_vp]),
+    ("apd_set_timing", C.c_int, [_vp, C.c_int]),
+    ("apd_last_kernel_ms", C.c_float, [_vp]),
+    ("apd_set_variant", C.c_int, [_vp, C.c_int]),
+    ("apd_selftest", C.c_int, [_vp]),
+    ("apd_discovery_alignment_params", C.c_int, [C.POINTER(AlignConfig), C.c_uint64, C.POINTER(AlignmentParamsC)]),
+    ("apd_batch_create", C.c_int, [_vp, _vp, _u64p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_vp)]),
+    ("apd_batch_destroy", C.c_int, [_vp]),
+    ("apd_batch_len", C.c_uint32, [_vp]),
+    ("apd_align_all", C.c_int, [_vp, _vp, C.POINTER(AlignConfig), _f32p]),
+    ("apd_align_all_device_async", C.c_int, [_vp, _vp, C.POINTER(AlignConfig), _vp]),
+    ("apd_tile_size", C.c_uint32, []),
+    ("apd_num_tiles", C.c_uint64, [C.c_uint32]),
+    ("apd_rank_tiles", C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint32]),
+    ("apd_slab_floats", C.c_uint64, [C.c_uint32, C.c_uint32]),
+    ("apd_align_tiles_async", C.c_int, [_vp, _vp, C.POINTER(AlignConfig), C.c_uint32, C.c_uint32, _vp]),
+    ("apd_unpack_tiles_async", C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _vp]),
+    ("apd_align_work", C.c_int, [_u64p, C.c_uint32, C.c_uint32, C.POINTER(AlignConfig), C.c_uint32, C.c_uint32,
+                                 _u64p, _u64p, _u64p]),
+    ("apd_align_pair", C.c_int, [_vp, _f32p, C.c_uint64, _f32p, C.c_uint64, C.c_uint32,
+                                 C.POINTER(AlignmentParamsC), _f32p]),
+    ("apd_percentile", C.c_int, [_vp, _vp, C.c_uint64, C.c_float, C.c_int, _f32p]),
+    ("apd_clustering", C.c_int, [_vp, _vp, C.c_int, C.c_uint32, C.c_float, C.POINTER(ClusterOp), _u32p, _u32p,
+                                 _u32p, _f32p]),
+    ("apd_cluster_sets", C.c_int, [C.POINTER(ClusterOp), C.c_uint32, _u32p, C.c_uint32, C.c_uint32, _u32p, _u32p,
+                                   _u32p]),
+    ("apd_encode", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, _f32p, _f32p, C.c_uint32, C.c_int, _vp]),
+    ("apd_cepstrum", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _vp, _u64p,
+                               _u32p]),
+]
+
+_lib = None
+
+
+def lib():
+    """Loads libapd_hip.so; raises OSError loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, ctx_handle=None):
+    if status != APD_OK:
+        detail = ""
+        if ctx_handle is not None and status == APD_ERR_HIP:
+            detail = lib().apd_last_error(ctx_handle).decode()
+        raise ApdError(status, detail)
+
+
+class Context:
+    """apd_context: one GPU, one HIP stream."""
+
+    def __init__(self, device=0, stream=None):
+        self.handle = _vp()
+        check(lib().apd_create(int(device), C.byref(self.handle)))
+        if stream is not None:
+            check(lib().apd_set_stream(self.handle, _vp(int(stream))), self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().apd_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(lib().apd_synchronize(self.handle), self.handle)
+
+    def set_timing(self, on=True):
+        check(lib().apd_set_timing(self.handle, int(bool(on))))
+
+    def last_kernel_ms(self):
+        return float(lib().apd_last_kernel_ms(self.handle))
+
+    def set_variant(self, v):
+        check(lib().apd_set_variant(self.handle, int(v)))
+
+    def selftest(self):
+        check(lib().apd_selftest(self.handle), self.handle)
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx

@@ -1,0 +1,444 @@
+// C ABI of libapd_hip.so (include/apd.h): context, resident batches, tile sharding and the
+// host-side plumbing around the alignment kernels.  No torch, no CPU fallback.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <new>
+
+#include "apd_internal.h"
+
+using namespace apd;
+
+namespace {
+
+#define HIP_TRY(ctx, call)                                                             \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e_);     \
+            return e_ == hipErrorOutOfMemory ? APD_ERR_OOM : APD_ERR_HIP;              \
+        }                                                                              \
+    } while (0)
+
+int ensure_ws(apd_context *ctx, void **p, size_t *have, size_t need)
+{
+    if (*have >= need && *p) return APD_OK;
+    if (*p) { HIP_TRY(ctx, hipFree(*p)); *p = nullptr; *have = 0; }
+    HIP_TRY(ctx, hipMalloc(p, need));
+    *have = need;
+    return APD_OK;
+}
+
+uint32_t tiles_side(uint32_t n_seq) { return (n_seq + kTile - 1) / kTile; }
+
+void rank_tile_list(uint32_t n_seq, uint32_t rank, uint32_t world, std::vector<uint2> &out)
+{
+    out.clear();
+    const uint32_t side = tiles_side(n_seq);
+    uint64_t g = 0;
+    for (uint32_t ta = 0; ta < side; ++ta)
+        for (uint32_t tb = ta; tb < side; ++tb, ++g)
+            if (g % world == rank) out.push_back(make_uint2(ta, tb));
+}
+
+// cells visited by alignments.rs:174-175 for lengths (n, m) and half-width w:
+// #{(i,j) in [1,n]x[1,m] : -w <= j-i <= w-1}
+uint64_t tri_count(uint64_t n, uint64_t m, uint64_t k)   // #{(i,j): j - i >= k}, k >= 0
+{
+    if (m <= k) return 0;
+    const uint64_t q = m - k, l = std::min(n, q);
+    return l * q - l * (l - 1) / 2;
+}
+uint64_t band_cells(uint64_t n, uint64_t m, uint64_t w)
+{
+    return n * m - tri_count(n, m, w) - tri_count(m, n, w + 1);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ context
+
+extern "C" const char *apd_status_string(int s)
+{
+    switch (s) {
+        case APD_OK: return "ok";
+        case APD_ERR_INVALID_ARG: return "invalid argument";
+        case APD_ERR_NO_DEVICE: return "no gfx950 HIP device";
+        case APD_ERR_HIP: return "HIP runtime error";
+        case APD_ERR_OOM: return "out of device memory";
+        case APD_ERR_EMPTY_SEQUENCE: return "zero-length sequence (undefined in the reference, alignments.rs:120)";
+        case APD_ERR_BAND_TOO_WIDE: return "warping band too wide for one wavefront";
+        case APD_ERR_INDEX: return "percentile index out of range (the reference panics, numerics.rs:132)";
+        case APD_ERR_UNSUPPORTED: return "unsupported";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int apd_create(int device, apd_context **out)
+{
+    if (!out) return APD_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return APD_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return APD_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return APD_ERR_NO_DEVICE;   // kernels are built for gfx950 only
+    apd_context *ctx = new (std::nothrow) apd_context();
+    if (!ctx) return APD_ERR_OOM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return APD_ERR_HIP;
+    }
+    ctx->own_stream = true;
+    hipEventCreate(&ctx->ev0);
+    hipEventCreate(&ctx->ev1);
+    *out = ctx;
+    return APD_OK;
+}
+
+extern "C" int apd_destroy(apd_context *ctx)
+{
+    if (!ctx) return APD_ERR_INVALID_ARG;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->ws_tiles) hipFree(ctx->ws_tiles);
+    if (ctx->ws_slab) hipFree(ctx->ws_slab);
+    if (ctx->ws_misc) hipFree(ctx->ws_misc);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return APD_OK;
+}
+
+extern "C" int apd_set_stream(apd_context *ctx, void *hip_stream)
+{
+    if (!ctx) return APD_ERR_INVALID_ARG;
+    if (ctx->own_stream && ctx->stream) { hipStreamSynchronize(ctx->stream); hipStreamDestroy(ctx->stream); }
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return APD_OK;
+}
+
+extern "C" int apd_synchronize(apd_context *ctx)
+{
+    if (!ctx) return APD_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return APD_OK;
+}
+
+extern "C" const char *apd_last_error(apd_context *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+extern "C" int apd_set_timing(apd_context *ctx, int enabled)
+{
+    if (!ctx) return APD_ERR_INVALID_ARG;
+    ctx->timing = enabled != 0;
+    ctx->timed = false;
+    return APD_OK;
+}
+
+extern "C" float apd_last_kernel_ms(apd_context *ctx)
+{
+    if (!ctx || !ctx->timed) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+extern "C" int apd_set_variant(apd_context *ctx, int variant)
+{
+    if (!ctx) return APD_ERR_INVALID_ARG;
+    ctx->variant = variant;
+    return APD_OK;
+}
+
+extern "C" int apd_selftest(apd_context *ctx)
+{
+    if (!ctx) return APD_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_ws(ctx, &ctx->ws_misc, &ctx->ws_misc_bytes, 256);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ws_misc, 0, sizeof(int), ctx->stream));
+    HIP_TRY(ctx, launch_selftest((int *)ctx->ws_misc, ctx->stream));
+    int ok = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&ok, ctx->ws_misc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ok) { ctx->last_error = "DPP wave_shr/wave_shl self-test failed"; return APD_ERR_HIP; }
+    return APD_OK;
+}
+
+// --------------------------------------------------------------------- Discovery::alignment_params
+
+extern "C" int apd_discovery_alignment_params(const apd_align_config *cfg, uint64_t n_size, apd_alignment_params *out)
+{
+    if (!cfg || !out) return APD_ERR_INVALID_ARG;
+    const float p = cfg->warping_band_percentage * (float)n_size;        // discovery.rs:40
+    uint64_t band;
+    if (!(p > 0.0f)) band = 0;
+    else if (p >= 18446744073709551616.0f) band = UINT64_MAX;
+    else band = (uint64_t)p;
+    out->warping_band = band;
+    out->insertion_penalty = cfg->insertion_penalty;                     // :41
+    out->match_penalty = cfg->match_penalty;                             // :42
+    out->deletion_penalty = cfg->deletion_penalty;                       // :43
+    return APD_OK;
+}
+
+// ------------------------------------------------------------------------------------- batch
+
+extern "C" int apd_batch_create(apd_context *ctx, const float *frames, const uint64_t *offsets, uint32_t n_seq,
+                                uint32_t dim, int frames_on_device, apd_batch **out)
+{
+    if (!ctx || !offsets || !out || dim == 0 || dim > 1024) return APD_ERR_INVALID_ARG;
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t total = offsets[n_seq];
+    if (total > 0 && !frames) return APD_ERR_INVALID_ARG;
+    if (total >= (1ull << 32) || offsets[0] != 0) return APD_ERR_INVALID_ARG;
+    apd_batch *b = new (std::nothrow) apd_batch();
+    if (!b) return APD_ERR_OOM;
+    b->ctx = ctx; b->n_seq = n_seq; b->dim = dim; b->dpad = (dim + 3) & ~3u; b->total_frames = total;
+    b->offsets.assign(offsets, offsets + n_seq + 1);
+    b->min_len = 0xFFFFFFFFu; b->max_len = 0;
+    std::vector<uint32_t> off32(n_seq + 1);
+    for (uint32_t s = 0; s <= n_seq; ++s) off32[s] = (uint32_t)offsets[s];
+    for (uint32_t s = 0; s < n_seq; ++s) {
+        if (offsets[s + 1] < offsets[s]) { delete b; return APD_ERR_INVALID_ARG; }
+        const uint32_t len = (uint32_t)(offsets[s + 1] - offsets[s]);
+        b->min_len = std::min(b->min_len, len);
+        b->max_len = std::max(b->max_len, len);
+    }
+    if (n_seq == 0) b->min_len = 0;
+    auto fail = [&](int rc) { apd_batch_destroy(b); return rc; };
+    const size_t padded_bytes = std::max<size_t>((size_t)total * b->dpad * sizeof(float), 16);
+    if (hipMalloc((void **)&b->d_frames, padded_bytes) != hipSuccess) return fail(APD_ERR_OOM);
+    if (hipMalloc((void **)&b->d_seq_off, (n_seq + 1) * sizeof(uint32_t)) != hipSuccess) return fail(APD_ERR_OOM);
+    if (hipMemcpyAsync(b->d_seq_off, off32.data(), (n_seq + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return fail(APD_ERR_HIP);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(APD_ERR_HIP);    // off32 is a stack-lifetime buffer
+    if (total > 0) {
+        const float *d_src = frames;
+        float *d_tmp = nullptr;
+        if (!frames_on_device) {
+            if (hipMalloc((void **)&d_tmp, (size_t)total * dim * sizeof(float)) != hipSuccess) return fail(APD_ERR_OOM);
+            if (hipMemcpyAsync(d_tmp, frames, (size_t)total * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+                hipFree(d_tmp);
+                return fail(APD_ERR_HIP);
+            }
+            d_src = d_tmp;
+        }
+        hipError_t e = launch_pad(d_src, b->d_frames, total, dim, b->dpad, ctx->stream);
+        if (d_tmp) { hipStreamSynchronize(ctx->stream); hipFree(d_tmp); }
+        if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return fail(APD_ERR_HIP); }
+    }
+    *out = b;
+    return APD_OK;
+}
+
+extern "C" int apd_batch_destroy(apd_batch *b)
+{
+    if (!b) return APD_ERR_INVALID_ARG;
+    if (b->ctx) { hipSetDevice(b->ctx->device); hipStreamSynchronize(b->ctx->stream); }
+    for (auto &kv : b->tile_cache) hipFree(kv.second.first);
+    if (b->d_frames) hipFree(b->d_frames);
+    if (b->d_seq_off) hipFree(b->d_seq_off);
+    delete b;
+    return APD_OK;
+}
+
+extern "C" uint32_t apd_batch_len(const apd_batch *b) { return b ? b->n_seq : 0; }
+
+// ------------------------------------------------------------------------------------- tiles
+
+extern "C" uint32_t apd_tile_size(void) { return kTile; }
+
+extern "C" uint64_t apd_num_tiles(uint32_t n_seq)
+{
+    const uint64_t side = tiles_side(n_seq);
+    return side * (side + 1) / 2;
+}
+
+extern "C" uint64_t apd_rank_tiles(uint32_t n_seq, uint32_t rank, uint32_t world)
+{
+    if (world == 0 || rank >= world) return 0;
+    const uint64_t t = apd_num_tiles(n_seq);
+    return t / world + (rank < t % world ? 1 : 0);
+}
+
+extern "C" uint64_t apd_slab_floats(uint32_t n_seq, uint32_t world)
+{
+    if (world == 0) return 0;
+    const uint64_t t = apd_num_tiles(n_seq);
+    return ((t + world - 1) / world) * 2 * kSlotsPerTile;
+}
+
+static int check_lengths(const apd_batch *b)
+{
+    if (b->n_seq > 0 && b->min_len == 0) return APD_ERR_EMPTY_SEQUENCE;
+    return APD_OK;
+}
+
+static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const BandSpec &band, uint32_t rank,
+                            uint32_t world, float *d_slab)
+{
+    if (!ctx || !batch || !d_slab || world == 0 || rank >= world || batch->ctx != ctx) return APD_ERR_INVALID_ARG;
+    int rc = check_lengths(batch);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    auto &entry = batch->tile_cache[((uint64_t)rank << 32) | world];
+    if (!entry.first) {
+        std::vector<uint2> tiles;
+        rank_tile_list(batch->n_seq, rank, world, tiles);
+        entry.second = (uint32_t)tiles.size();
+        HIP_TRY(ctx, hipMalloc((void **)&entry.first, std::max<size_t>(tiles.size(), 1) * sizeof(uint2)));
+        if (!tiles.empty()) {
+            HIP_TRY(ctx, hipMemcpyAsync(entry.first, tiles.data(), tiles.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    AlignLaunch L{};
+    L.d_frames = batch->d_frames; L.d_seq_off = batch->d_seq_off; L.d_tiles = entry.first; L.n_tiles = entry.second;
+    L.n_seq = batch->n_seq; L.dim = batch->dim; L.dpad = batch->dpad; L.band = band; L.d_slab = d_slab;
+    L.variant = ctx->variant;
+    // upper bound of w over all pairs: the band is monotone in max(n,m), the gap is at most max_len - min_len
+    {
+        const uint32_t band_ub = band.use_explicit ? band.explicit_band : host_band_from_pct(band.pct, batch->max_len);
+        const uint32_t bclamp = std::min(band_ub, batch->max_len);
+        L.w_max = std::max(bclamp, batch->max_len - batch->min_len) + 2;
+    }
+    if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    int status = APD_OK;
+    hipError_t e = launch_align(L, ctx->stream, ctx->last_error, &status);
+    if (e != hipSuccess) { ctx->last_error = std::string("launch_align: ") + hipGetErrorString(e); return APD_ERR_HIP; }
+    if (status != APD_OK) return status;
+    if (ctx->timing) { HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream)); ctx->timed = true; }
+    return APD_OK;
+}
+
+static BandSpec band_from_cfg(const apd_align_config *cfg)
+{
+    BandSpec b{};
+    b.pct = cfg->warping_band_percentage; b.use_explicit = 0; b.explicit_band = 0;
+    b.ins = cfg->insertion_penalty; b.del = cfg->deletion_penalty; b.mat = cfg->match_penalty;
+    return b;
+}
+
+extern "C" int apd_align_tiles_async(apd_context *ctx, const apd_batch *batch, const apd_align_config *cfg,
+                                     uint32_t rank, uint32_t world, float *d_slab)
+{
+    if (!cfg) return APD_ERR_INVALID_ARG;
+    return align_tiles_impl(ctx, batch, band_from_cfg(cfg), rank, world, d_slab);
+}
+
+extern "C" int apd_unpack_tiles_async(apd_context *ctx, uint32_t n_seq, uint32_t world, const float *d_gathered,
+                                      float *d_out)
+{
+    if (!ctx || !d_gathered || !d_out || world == 0) return APD_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemsetAsync(d_out, 0, (size_t)n_seq * n_seq * sizeof(float), ctx->stream));   // alignments.rs:21-23
+    HIP_TRY(ctx, launch_unpack(d_gathered, d_out, n_seq, world, apd_slab_floats(n_seq, world), ctx->stream));
+    return APD_OK;
+}
+
+static int align_all_device_impl(apd_context *ctx, const apd_batch *batch, const BandSpec &band, float *d_out)
+{
+    if (!ctx || !batch || !d_out) return APD_ERR_INVALID_ARG;
+    const size_t slab_bytes = std::max<size_t>(apd_slab_floats(batch->n_seq, 1) * sizeof(float), 16);
+    int rc = ensure_ws(ctx, &ctx->ws_slab, &ctx->ws_slab_bytes, slab_bytes);
+    if (rc) return rc;
+    rc = align_tiles_impl(ctx, batch, band, 0, 1, (float *)ctx->ws_slab);
+    if (rc) return rc;
+    return apd_unpack_tiles_async(ctx, batch->n_seq, 1, (const float *)ctx->ws_slab, d_out);
+}
+
+extern "C" int apd_align_all_device_async(apd_context *ctx, const apd_batch *batch, const apd_align_config *cfg,
+                                          float *d_out)
+{
+    if (!cfg) return APD_ERR_INVALID_ARG;
+    return align_all_device_impl(ctx, batch, band_from_cfg(cfg), d_out);
+}
+
+extern "C" int apd_align_all(apd_context *ctx, const apd_batch *batch, const apd_align_config *cfg, float *out)
+{
+    if (!ctx || !batch || !cfg || (!out && batch->n_seq)) return APD_ERR_INVALID_ARG;
+    if (batch->n_seq == 0) return APD_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)batch->n_seq * batch->n_seq * sizeof(float);
+    float *d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&d_out, bytes));
+    int rc = align_all_device_impl(ctx, batch, band_from_cfg(cfg), d_out);
+    if (rc == APD_OK) {
+        hipError_t e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); rc = APD_ERR_HIP; }
+    }
+    hipFree(d_out);
+    return rc;
+}
+
+extern "C" int apd_align_pair(apd_context *ctx, const float *x, uint64_t n, const float *y, uint64_t m, uint32_t dim,
+                              const apd_alignment_params *params, float *score)
+{
+    if (!ctx || !params || !score || dim == 0) return APD_ERR_INVALID_ARG;
+    if (n == 0 && m == 0) { *score = INFINITY; return APD_OK; }           // alignments.rs:117-118
+    if (n == 0 || m == 0) return APD_ERR_EMPTY_SEQUENCE;                  // usize underflow at :120
+    if (!x || !y) return APD_ERR_INVALID_ARG;
+    std::vector<float> frames((n + m) * (size_t)dim);
+    std::memcpy(frames.data(), x, n * (size_t)dim * sizeof(float));
+    std::memcpy(frames.data() + n * (size_t)dim, y, m * (size_t)dim * sizeof(float));
+    const uint64_t offsets[3] = {0, n, n + m};
+    apd_batch *b = nullptr;
+    int rc = apd_batch_create(ctx, frames.data(), offsets, 2, dim, 0, &b);
+    if (rc) return rc;
+    BandSpec band{};
+    band.use_explicit = 1;
+    band.explicit_band = params->warping_band > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)params->warping_band;
+    band.ins = params->insertion_penalty; band.del = params->deletion_penalty; band.mat = params->match_penalty;
+    float *d_out = nullptr;
+    if (hipMalloc((void **)&d_out, 4 * sizeof(float)) != hipSuccess) { apd_batch_destroy(b); return APD_ERR_OOM; }
+    rc = align_all_device_impl(ctx, b, band, d_out);
+    float host[4] = {0, 0, 0, 0};
+    if (rc == APD_OK) {
+        hipError_t e = hipMemcpyAsync(host, d_out, sizeof(host), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); rc = APD_ERR_HIP; }
+    }
+    hipFree(d_out);
+    apd_batch_destroy(b);
+    if (rc == APD_OK) *score = host[1];                                   // out[0*2+1] = score(x, y)
+    return rc;
+}
+
+// ------------------------------------------------------------------------------- work accounting
+
+extern "C" int apd_align_work(const uint64_t *offsets, uint32_t n_seq, uint32_t dim, const apd_align_config *cfg,
+                              uint32_t rank, uint32_t world, uint64_t *pairs, uint64_t *cells, uint64_t *alg_bytes)
+{
+    if (!offsets || !cfg || world == 0 || rank >= world) return APD_ERR_INVALID_ARG;
+    const BandSpec band = band_from_cfg(cfg);
+    std::vector<uint2> tiles;
+    rank_tile_list(n_seq, rank, world, tiles);
+    uint64_t np = 0, nc = 0, nb = 0;
+    for (const uint2 &t : tiles)
+        for (uint32_t sa = 0; sa < kTile; ++sa)
+            for (uint32_t sb = 0; sb < kTile; ++sb) {
+                const uint32_t a = t.x * kTile + sa, b = t.y * kTile + sb;
+                if (!(a < b && b < n_seq)) continue;
+                const uint64_t n = offsets[a + 1] - offsets[a], m = offsets[b + 1] - offsets[b];
+                if (n == 0 || m == 0) return APD_ERR_EMPTY_SEQUENCE;
+                const uint64_t mx = std::max(n, m), gap = mx - std::min(n, m);
+                uint64_t bnd = host_band_from_pct(band.pct, (uint32_t)mx);
+                const uint64_t w = std::max(bnd, gap) + 2;                // alignments.rs:173 (unclamped: same cell set)
+                np += 2;                                                  // both ordered pairs (alignments.rs:50-51)
+                nc += band_cells(n, m, w) + band_cells(m, n, w);
+                nb += 2 * (4ull * dim * (n + m) + 4);
+            }
+    if (pairs) *pairs = np;
+    if (cells) *cells = nc;
+    if (alg_bytes) *alg_bytes = nb;
+    return APD_OK;
+}

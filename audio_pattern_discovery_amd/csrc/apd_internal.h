@@ -1,0 +1,91 @@
+// Internal declarations shared by the HIP translation units of libapd_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/apd.h"
+
+namespace apd {
+
+constexpr int kTile = 16;              // sequences per tile side -> 256 pair slots per tile
+constexpr int kSlotsPerTile = kTile * kTile;
+constexpr int kWave = 64;
+
+// How the per-pair Sakoe-Chiba band is obtained.
+struct BandSpec {
+    float pct;                 // Discovery.warping_band_percentage (discovery.rs:40)
+    uint32_t explicit_band;    // AlignmentParams.warping_band when use_explicit
+    int use_explicit;
+    float ins, del, mat;
+};
+
+// One launch of the fused-pair alignment over a list of tiles.
+struct AlignLaunch {
+    const float *d_frames;       // [total_frames][dpad] zero padded
+    const uint32_t *d_seq_off;   // [n_seq+1] frame offsets
+    const uint2 *d_tiles;        // [n_tiles] (tile_a, tile_b), tile_a <= tile_b
+    uint32_t n_tiles;
+    uint32_t n_seq;
+    uint32_t dim, dpad;
+    BandSpec band;
+    float *d_slab;               // [n_tiles][2][kTile][kTile]
+    uint32_t w_max;              // upper bound of w over the pairs of this launch
+    int variant;                 // 0 auto
+};
+
+hipError_t launch_align(const AlignLaunch &L, hipStream_t stream, std::string &err, int *status);
+hipError_t launch_pad(const float *d_src, float *d_dst, uint64_t n_frames, uint32_t dim, uint32_t dpad,
+                      hipStream_t stream);
+hipError_t launch_unpack(const float *d_gathered, float *d_out, uint32_t n_seq, uint32_t world,
+                         uint64_t slab_floats, hipStream_t stream);
+hipError_t launch_selftest(int *d_result, hipStream_t stream);
+
+// Host-side mirrors of the device band arithmetic (bit-identical f32 product).
+inline uint32_t host_band_from_pct(float pct, uint32_t len)
+{
+    float p = pct * (float)len;                 // discovery.rs:40
+    if (!(p > 0.0f)) return 0;                  // NaN / negative saturate to 0 (Rust `as usize`)
+    if (p >= 4294967040.0f) return 0xFFFFFFFFu;
+    return (uint32_t)p;
+}
+inline uint32_t host_w(const BandSpec &b, uint32_t n, uint32_t m)
+{
+    uint32_t mx = n > m ? n : m, gap = n > m ? n - m : m - n;
+    uint32_t band = b.use_explicit ? b.explicit_band : host_band_from_pct(b.pct, mx);
+    if (band > mx) band = mx;                   // any band >= max(n,m) already covers the full matrix
+    return (band > gap ? band : gap) + 2;       // alignments.rs:173
+}
+
+}  // namespace apd
+
+struct apd_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int variant = 0;
+    std::string last_error;
+    // reusable device workspaces
+    void *ws_tiles = nullptr; size_t ws_tiles_bytes = 0;
+    void *ws_slab = nullptr; size_t ws_slab_bytes = 0;
+    void *ws_misc = nullptr; size_t ws_misc_bytes = 0;
+};
+
+struct apd_batch {
+    apd_context *ctx = nullptr;
+    uint32_t n_seq = 0, dim = 0, dpad = 0;
+    uint64_t total_frames = 0;
+    float *d_frames = nullptr;        // padded
+    uint32_t *d_seq_off = nullptr;
+    std::vector<uint64_t> offsets;    // host copy
+    uint32_t min_len = 0, max_len = 0;
+    // device-resident tile lists, keyed (rank << 32 | world)
+    mutable std::map<uint64_t, std::pair<uint2 *, uint32_t>> tile_cache;
+};

@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: all-pairs Sakoe-Chiba-banded DTW distance matrix (reference
+src/alignments.rs:31-67) on synthetic MFCC-like sequences, one process per GPU.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one full pass of the path over the resident batch: repack the [sum len][D] frames into
+the kernels' padded layout, fused-pair DTW over this rank's pair tiles, ONE all-gather of the
+packed tile slabs (RCCL via torch.distributed's "nccl" backend), unpack into the N x N matrix.
+The pair set is fixed as ranks are added (strong scaling).  torch is plumbing only: device
+buffers, the stream and the collective; the compute is libapd_hip.so through its C ABI.
+
+Prints ONE JSON line on rank 0 (metric: DTW cell-updates/s, whole job), with
+  roofline     -- algorithmic bytes (4*D*(n+m)+4 per ordered pair) / measured kernel time vs 8 TB/s
+  cpu_baseline -- the CPU oracle (a port of the reference's algorithm) timed on a bounded sample
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# BASELINE.json configs: name -> (n_seq, nominal_len, dim, band_pct)
+WORKLOADS = {
+    "cfg1": dict(n_seq=64, length=256, dim=13, pct=1.0,
+                 desc="64 seq len~256 D=13 full DTW (reference CPU-runnable case)"),
+    "cfg2": dict(n_seq=1024, length=512, dim=13, pct=0.0625,
+                 desc="1024 seq len~512 D=13 MFCC, Sakoe-Chiba band=32"),
+    "cfg3": dict(n_seq=4096, length=1024, dim=13, pct=0.0625,
+                 desc="4096 seq len~1024 D=13 MFCC, band=64, all-pairs distance matrix"),
+    "cfg4": dict(n_seq=4096, length=1024, dim=8, pct=0.0625,
+                 desc="4096 seq len~1024 D=8 autoencoder embeddings, band=64"),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("APD_WORKLOAD", "cfg3"), choices=sorted(WORKLOADS))
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = auto)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per leg (0 = skip)")
+    ap.add_argument("--verify", type=int, default=64, help="entries re-checked against the oracle after timing")
+    return ap.parse_args()
+
+
+def host_threads():
+    """CPU threads for the oracle legs: the GPU box grants 16 cores per GPU."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, 16))
+
+
+def cpu_baseline(frames, offsets, wl, seconds):
+    """Times the CPU oracle (oracle/apd_oracle.c, kind = "port") on a bounded random sample of
+    ordered pairs with every host core; returns the JSON object."""
+    from oracle import binding as oracle
+    cores = host_threads()
+    rng = np.random.default_rng(1234)
+    n = wl["n_seq"]
+
+    def sample(k):
+        pi = rng.integers(0, n, k).astype(np.uint32)
+        pj = (pi + 1 + rng.integers(0, n - 1, k)).astype(np.uint32) % n
+        return pi, pj
+
+    out = {}
+    for name, hm in (("dense", False), ("hashmap", True)):
+        pi, pj = sample(cores * 4)
+        t0 = time.perf_counter()
+        _, cells = oracle.align_sample(frames, offsets, pi, pj, wl["pct"], workers=cores, hashmap=hm)
+        dt = max(time.perf_counter() - t0, 1e-6)
+        k = int(max(cores * 4, min(seconds / dt * len(pi) * 0.8, 2_000_000)))
+        pi, pj = sample(k)
+        t0 = time.perf_counter()
+        _, cells = oracle.align_sample(frames, offsets, pi, pj, wl["pct"], workers=cores, hashmap=hm)
+        dt = time.perf_counter() - t0
+        out[name] = (cells / dt, k, dt)
+    return {
+        "value": out["dense"][0], "unit": "cell-updates/s", "cores": cores, "kind": "port",
+        "sample": "%d random ordered pairs of the same workload, dense rolling-row oracle, %.1f s"
+                  % (out["dense"][1], out["dense"][2]),
+        "reference_like_value": out["hashmap"][0],
+        "reference_like_sample": "%d pairs with the reference's per-pair hash-map cost structure, %.1f s"
+                                 % (out["hashmap"][1], out["hashmap"][2]),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (see the docstring)")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from audio_pattern_discovery_amd import _lib, synth
+    from audio_pattern_discovery_amd.alignments import align_work
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    wl = WORKLOADS[args.workload]
+    n, dim = wl["n_seq"], wl["dim"]
+    frames, offsets = synth.make_sequences(n, wl["length"], dim, seed=0xA9D0 + int(args.workload[3:]))
+    L = _lib.lib()
+    cfg = _lib.AlignConfig(wl["pct"], 1.0, 1.0, 1.0)
+    pairs_all, cells_all, bytes_all = align_work(offsets, dim, cfg, 0, 1)
+    pairs_r, cells_r, bytes_r = align_work(offsets, dim, cfg, rank, world)
+
+    ctx = _lib.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    ctx.selftest()
+    ctx.set_variant(args.variant)
+    ctx.set_timing(True)
+    d_frames = torch.from_numpy(frames).to(dev)                      # inputs resident in HBM
+    off_c = np.ascontiguousarray(offsets, dtype=np.uint64)
+    slab_floats = int(L.apd_slab_floats(n, world))
+    d_slab = torch.zeros(slab_floats, dtype=torch.float32, device=dev)
+    d_gathered = torch.zeros(slab_floats * world, dtype=torch.float32, device=dev) if world > 1 else d_slab
+    d_out = torch.empty(n * n, dtype=torch.float32, device=dev)
+    kernel_ms = []
+
+    def step():
+        batch = C.c_void_p()
+        _lib.check(L.apd_batch_create(ctx.handle, C.c_void_p(d_frames.data_ptr()), off_c.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                      n, dim, 1, C.byref(batch)), ctx.handle)
+        _lib.check(L.apd_align_tiles_async(ctx.handle, batch, C.byref(cfg), rank, world, C.c_void_p(d_slab.data_ptr())),
+                   ctx.handle)
+        if world > 1:
+            dist.all_gather_into_tensor(d_gathered, d_slab)          # the one collective (RCCL over xGMI)
+        _lib.check(L.apd_unpack_tiles_async(ctx.handle, n, world, C.c_void_p(d_gathered.data_ptr()),
+                                            C.c_void_p(d_out.data_ptr())), ctx.handle)
+        return batch
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        L.apd_batch_destroy(step())
+    fence()
+    t0 = time.perf_counter()
+    batches = []
+    for _ in range(args.steps):
+        batches.append(step())
+        ms = ctx.last_kernel_ms()                                    # syncs on the kernel's end event only
+        kernel_ms.append(ms)
+    fence()
+    elapsed = time.perf_counter() - t0
+    for b in batches:
+        L.apd_batch_destroy(b)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        result = d_out.cpu().numpy().reshape(n, n)
+        verify = None
+        if args.verify > 0:
+            from oracle import binding as oracle
+            rng = np.random.default_rng(7)
+            pi = rng.integers(0, n, args.verify).astype(np.uint32)
+            pj = (pi + 1 + rng.integers(0, n - 1, args.verify)).astype(np.uint32) % n
+            want, _ = oracle.align_sample(frames, offsets, pi, pj, wl["pct"], workers=host_threads())
+            verify = float(np.max(np.abs(result[pi, pj] - want) / np.maximum(np.abs(want), 1e-30)))
+        k_ms = float(np.mean(kernel_ms))
+        achieved = bytes_r / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "DTW cell-updates/sec (whole node)", "value": cells_all * args.steps / elapsed,
+            "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "n_seq": n, "nominal_len": wl["length"],
+                       "dim": dim, "warping_band_percentage": wl["pct"], "ordered_pairs": pairs_all,
+                       "cells_per_step": cells_all, "sharding": "pair tiles 16x16, cyclic over %d ranks, 1 all-gather" % world,
+                       "kernel_variant": args.variant},
+            "wall_clock_matrix_s": elapsed / args.steps,
+            "pairs_per_s": pairs_all * args.steps / elapsed,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "dtw_fused (rank 0 share: %d ordered pairs)" % pairs_r,
+                         "kernel_ms": k_ms, "alg_bytes_per_launch": bytes_r,
+                         "kernel_cells_per_s": cells_r / (k_ms * 1e-3)},
+            "max_rel_err_vs_oracle": verify,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(frames, offsets, wl, args.cpu_seconds)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

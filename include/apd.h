@@ -1,0 +1,163 @@
+/*
+ * apd.h -- C ABI of the MI355X-native alignment + clustering path.
+ *
+ * Drop-in boundary for the one hot path of dkohlsdorf/audio_pattern_discovery:
+ * AlignmentWorkers::align_all (src/alignments.rs:31-67) feeding
+ * AgglomerativeClustering::clustering (src/clustering.rs:81-110), plus the two feature
+ * companions NDSequence::new (src/spectrogram.rs:31-94) and AutoEncoder::predict
+ * (src/neural.rs:55-71).  The reference has no FFI of its own (one Rust crate, plain `pub`
+ * items called from src/main.rs:187-203); each entry point below names the Rust item a
+ * binding crate would route to it -- INTEGRATION.md shows that binding.
+ *
+ * Conventions: plain pointers and sizes only; every function returns an apd_status
+ * (0 = OK, negative = error), never throws or aborts across the boundary; the caller owns
+ * host buffers, the library owns device buffers behind the opaque handles; functions taking
+ * a context are synchronous unless their name ends in _async.  Pointers named d_* are
+ * DEVICE pointers (HBM of the context's GPU), everything else is host memory.
+ *
+ * There is no CPU fallback: without a gfx950 device apd_create fails with
+ * APD_ERR_NO_DEVICE and nothing else can be called.
+ */
+#ifndef APD_H
+#define APD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum apd_status {
+    APD_OK = 0,
+    APD_ERR_INVALID_ARG = -1,
+    APD_ERR_NO_DEVICE = -2,      /* no HIP device / not gfx950 */
+    APD_ERR_HIP = -3,            /* a HIP runtime call failed: apd_last_error() has the text */
+    APD_ERR_OOM = -4,
+    APD_ERR_EMPTY_SEQUENCE = -5, /* a zero-length sequence: the reference underflows usize at alignments.rs:120 */
+    APD_ERR_BAND_TOO_WIDE = -6,  /* 2*w+1 exceeds what one wavefront's LDS state can hold */
+    APD_ERR_INDEX = -7,          /* percentile index past the data: the reference panics at numerics.rs:132 */
+    APD_ERR_UNSUPPORTED = -8
+} apd_status;
+
+typedef struct apd_context apd_context;   /* one GPU + one HIP stream + workspaces */
+typedef struct apd_batch apd_batch;       /* Arc<Vec<NDSequence>> resident in HBM (alignments.rs:12) */
+
+/* The four Discovery fields the path reads (src/discovery.rs:17-20, project/config/Discovery.toml:17-20). */
+typedef struct apd_align_config {
+    float warping_band_percentage;
+    float insertion_penalty;
+    float deletion_penalty;
+    float match_penalty;
+} apd_align_config;
+
+/* AlignmentParams (src/alignments.rs:77-83). */
+typedef struct apd_alignment_params {
+    uint64_t warping_band;
+    float insertion_penalty;
+    float deletion_penalty;
+    float match_penalty;
+} apd_alignment_params;
+
+/* Merge (src/clustering.rs:8-13) and ClusteringOperation (src/clustering.rs:19-25). */
+enum { APD_SEQUENCE2SEQUENCE = 0, APD_SEQUENCE2CLUSTER = 1, APD_CLUSTER2SEQUENCE = 2, APD_CLUSTER2CLUSTER = 3 };
+typedef struct apd_cluster_op {
+    uint32_t merge_i;
+    uint32_t merge_j;
+    uint32_t into;
+    float distance;
+    uint32_t operation;
+} apd_cluster_op;
+
+/* ---- context ------------------------------------------------------------------------- */
+int apd_create(int device, apd_context **ctx);
+int apd_destroy(apd_context *ctx);
+/* Run on the caller's hipStream_t (e.g. torch's current stream) instead of the context's own. */
+int apd_set_stream(apd_context *ctx, void *hip_stream);
+int apd_synchronize(apd_context *ctx);
+const char *apd_status_string(int status);
+const char *apd_last_error(apd_context *ctx);
+/* Record HIP events around every alignment kernel launch; apd_last_kernel_ms returns the
+ * duration of the most recent one (ms, on the launch stream), < 0 if none was timed. */
+int apd_set_timing(apd_context *ctx, int enabled);
+float apd_last_kernel_ms(apd_context *ctx);
+/* Tuning knob for experiments: 0 = pick automatically.  See DESIGN.md "Kernel variants". */
+int apd_set_variant(apd_context *ctx, int variant);
+/* Device self-test of the cross-lane primitives the kernels rely on (DPP wave shifts). */
+int apd_selftest(apd_context *ctx);
+
+/* ---- Discovery::alignment_params (src/discovery.rs:38-45) ----------------------------- */
+int apd_discovery_alignment_params(const apd_align_config *cfg, uint64_t n_size, apd_alignment_params *out);
+
+/* ---- AlignmentWorkers::new (src/alignments.rs:17-26) ---------------------------------- */
+/* frames: packed [offsets[n_seq]][dim] f32 row-major (NDSequence.frames of every sequence,
+ * spectrogram.rs:16-17, back to back); offsets: n_seq+1 frame offsets.  If frames_on_device
+ * != 0, `frames` is a device pointer and stays owned by the caller (it is only read during
+ * this call).  The batch keeps its own HBM copy in the kernels' padded layout. */
+int apd_batch_create(apd_context *ctx, const float *frames, const uint64_t *offsets, uint32_t n_seq,
+                     uint32_t dim, int frames_on_device, apd_batch **batch);
+int apd_batch_destroy(apd_batch *batch);
+uint32_t apd_batch_len(const apd_batch *batch);
+
+/* ---- AlignmentWorkers::align_all (src/alignments.rs:31-67) ---------------------------- */
+/* out: n_seq*n_seq f32 row-major, out[i*n+j] = Alignment::score of (x = seq i, y = seq j),
+ * diagonal 0.0 (alignments.rs:21-23,51,57).  Blocking. */
+int apd_align_all(apd_context *ctx, const apd_batch *batch, const apd_align_config *cfg, float *out);
+/* Same, result left in HBM (d_out: n_seq*n_seq floats); asynchronous on the context's stream. */
+int apd_align_all_device_async(apd_context *ctx, const apd_batch *batch, const apd_align_config *cfg,
+                               float *d_out);
+
+/* Sharded form (the reference's static row blocks, alignments.rs:33-37, become pair tiles):
+ * the upper triangle of the n x n pair matrix is cut into apd_tile_size() x apd_tile_size()
+ * tiles; rank r of `world` owns tiles r, r+world, ...  Each rank fills one packed slab of
+ * apd_slab_floats() floats; after an all-gather of the `world` slabs (rank order) into
+ * d_gathered, apd_unpack_tiles_async scatters them into the n x n matrix. */
+uint32_t apd_tile_size(void);
+uint64_t apd_num_tiles(uint32_t n_seq);
+uint64_t apd_rank_tiles(uint32_t n_seq, uint32_t rank, uint32_t world);
+uint64_t apd_slab_floats(uint32_t n_seq, uint32_t world);
+int apd_align_tiles_async(apd_context *ctx, const apd_batch *batch, const apd_align_config *cfg,
+                          uint32_t rank, uint32_t world, float *d_slab);
+int apd_unpack_tiles_async(apd_context *ctx, uint32_t n_seq, uint32_t world, const float *d_gathered,
+                           float *d_out);
+
+/* Work accounting for the metric: cells = sum over ordered pairs of the
+ * cells alignments.rs:174-175 visits; alg_bytes = sum of 4*dim*(n+m)+4. */
+int apd_align_work(const uint64_t *offsets, uint32_t n_seq, uint32_t dim, const apd_align_config *cfg,
+                   uint32_t rank, uint32_t world, uint64_t *pairs, uint64_t *cells, uint64_t *alg_bytes);
+
+/* ---- Alignment::new + construct_alignment + score (src/alignments.rs:107-180) --------- */
+/* x: [n][dim], y: [m][dim] host.  *score = Alignment::score() after construct_alignment(x, y, params). */
+int apd_align_pair(apd_context *ctx, const float *x, uint64_t n, const float *y, uint64_t m, uint32_t dim,
+                   const apd_alignment_params *params, float *score);
+
+/* ---- numerics::percentile (src/numerics.rs:125-133) ----------------------------------- */
+/* x: len floats, host or (x_on_device != 0) device. */
+int apd_percentile(apd_context *ctx, const float *x, uint64_t len, float perc, int x_on_device, float *value);
+
+/* ---- AgglomerativeClustering::clustering (src/clustering.rs:81-110) ------------------- */
+/* distances: n*n host (or device if distances_on_device).  ops capacity >= n, roots capacity >= n.
+ * roots = dendrogram.clusters() in ascending id order (the reference returns a HashSet). */
+int apd_clustering(apd_context *ctx, const float *distances, int distances_on_device, uint32_t n,
+                   float perc, apd_cluster_op *ops, uint32_t *n_ops, uint32_t *roots, uint32_t *n_roots,
+                   float *threshold);
+/* AgglomerativeClustering::cluster_sets (src/clustering.rs:40-76); host-only bookkeeping.
+ * members capacity >= n, set_off capacity >= n_roots+1. */
+int apd_cluster_sets(const apd_cluster_op *ops, uint32_t n_ops, const uint32_t *roots, uint32_t n_roots,
+                     uint32_t n, uint32_t *members, uint32_t *set_off, uint32_t *n_sets);
+
+/* ---- companions ---------------------------------------------------------------------- */
+/* AutoEncoder::predict over every frame = NDSequence::encoded (src/neural.rs:55-71,
+ * src/spectrogram.rs:103-121).  x: [t][d_in]; w_encode: [d_in][latent] (Mat{flat, cols=latent},
+ * numerics.rs:171-174); b_encode: [latent]; out: [t][latent].  *_on_device selects HBM pointers
+ * for x and out. */
+int apd_encode(apd_context *ctx, const float *x, uint64_t t, uint32_t d_in, const float *w_encode,
+               const float *b_encode, uint32_t latent, int on_device, float *out);
+/* Cepstrum frames of NDSequence::new (src/spectrogram.rs:31-80).  Returns the frame count in
+ * *n_frames and bins per frame in *n_bins; out may be NULL to query sizes. */
+int apd_cepstrum(apd_context *ctx, const int16_t *samples, uint64_t n_samples, uint32_t fft_size,
+                 uint32_t fft_step, uint32_t filter_size, int on_device, float *out, uint64_t *n_frames,
+                 uint32_t *n_bins);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

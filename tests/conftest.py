@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:                # torch bundles its own HIP runtime: load it BEFORE libapd_hip.so pulls in /opt/rocm's,
+    import torch    # so that one process never holds two HIP runtimes (only matters for tests using both)
+except Exception:   # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

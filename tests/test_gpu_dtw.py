@@ -1,0 +1,190 @@
+"""GPU parity tests: the HIP alignment path through the C ABI vs the CPU oracle.
+
+Tolerance (BASELINE.json north_star): every finite distance within 1e-4 relative of the oracle,
+identical 0.0 diagonal and identical +INF pattern.  The kernels use an fma chain for the frame
+distance and v_sqrt_f32 (<= 1 ulp), so results are not bitwise equal to the two-rounding CPU code.
+"""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from audio_pattern_discovery_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ctx(apd):
+    c = apd.Context(0)
+    yield c
+    c.close()
+
+
+def assert_parity(got, want, rtol=RTOL):
+    got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
+    assert got.shape == want.shape
+    fin = np.isfinite(want)
+    assert np.array_equal(fin, np.isfinite(got)), "INF/NaN pattern differs"
+    assert np.array_equal(np.isposinf(want), np.isposinf(got))
+    zero = fin & (want == 0)
+    assert np.all(got[zero] == 0), "exact zeros (diagonal, identical sequences) must stay 0"
+    nz = fin & ~zero
+    if nz.any():
+        rel = np.abs(got[nz] - want[nz]) / np.abs(want[nz])
+        assert rel.max() <= rtol, "max rel err %.3e" % rel.max()
+
+
+def gpu_align_all(ctx, frames, offsets, dim, pct, ins=1.0, dele=1.0, mat=1.0, variant=0):
+    from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
+    from audio_pattern_discovery_amd.discovery import Discovery
+    ctx.set_variant(variant)
+    seqs = [NDSequence(s.reshape(-1, dim)) for s in synth.split(frames, offsets)]
+    w = AlignmentWorkers.new(seqs, ctx)
+    n = len(seqs)
+    out = w.align_all(Discovery(warping_band_percentage=pct, insertion_penalty=ins, deletion_penalty=dele,
+                                match_penalty=mat)).reshape(n, n).copy()
+    ctx.set_variant(0)
+    return out
+
+
+def test_selftest_cross_lane_primitives(ctx):
+    ctx.selftest()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "*.npz"))))
+def test_golden_vectors(ctx, path, variant):
+    g = np.load(path)
+    if "dist" not in g:
+        pytest.skip("companion fixture")
+    pct, ins, dele, mat, _ = [float(v) for v in g["params"]]
+    dim = g["frames"].shape[1]
+    got = gpu_align_all(ctx, g["frames"], g["offsets"], dim, pct, ins, dele, mat, variant)
+    assert_parity(got, g["dist"])
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("dim,pct,n_seq,length,jitter,integer,pens", [
+    (13, 0.0625, 40, 96, 3, False, (1, 1, 1)),        # band binds, w = band + 2
+    (13, 0.0625, 24, 200, 40, False, (1, 1, 1)),      # |n-m| > band: widening (alignments.rs:173)
+    (13, 1.0, 20, 64, 8, False, (1, 1, 1)),           # full DTW (shipped config)
+    (13, 0.0625, 30, 80, 5, True, (1, 1, 1)),         # integer features: exact ties in the select
+    (13, 0.25, 30, 80, 5, True, (0.5, 1.5, 0.75)),    # ties + non-unit penalties
+    (8, 0.0625, 33, 120, 3, False, (1, 1, 1)),        # autoencoder latents (cfg 4)
+    (10, 0.1, 17, 70, 9, False, (0.9, 1.1, 1.0)),     # shipped auto_encoder = 10
+    (26, 0.0625, 18, 90, 4, False, (1, 1, 1)),        # shipped ceps_filter = 32 -> 26 bins
+    (5, 0.2, 19, 50, 10, True, (1, 1, 1)),            # generic dims
+    (1, 0.0, 21, 30, 6, True, (1, 1, 1)),             # band 0 -> w = |n-m| + 2
+    (3, 1.0, 10, 300, 100, False, (1, 1, 1)),         # wide full band (C = 9 / generic)
+])
+def test_random_batches_match_oracle(ctx, oracle, variant, dim, pct, n_seq, length, jitter, integer, pens):
+    frames, offsets = synth.make_sequences(n_seq, length, dim, seed=dim * 1000 + n_seq, integer=integer, jitter=jitter)
+    want = oracle.align_all(frames, offsets, pct, *pens, workers=8)
+    got = gpu_align_all(ctx, frames, offsets, dim, pct, *pens, variant=variant)
+    assert_parity(got, want)
+    assert np.all(np.diag(got) == 0.0)                # alignments.rs:51
+
+
+def test_matrix_is_directed_when_band_binds(ctx, oracle):
+    # the band j-i in [-w, w-1] is asymmetric, so d(i,j) != d(j,i) in general: both triangles are computed
+    frames, offsets = synth.make_sequences(16, 150, 13, seed=99, jitter=12)
+    want = oracle.align_all(frames, offsets, 0.02, workers=8)
+    got = gpu_align_all(ctx, frames, offsets, 13, 0.02)
+    assert_parity(got, want)
+    assert np.array_equal(want != want.T, got != got.T) or np.abs(got - got.T).max() > 0
+
+
+def test_edge_lengths(ctx, oracle):
+    # lengths 1 and 2 (absent cell -> INF, n=m=1 -> 0.0), alignments.rs:116-125
+    rng = np.random.default_rng(5)
+    lens = [1, 1, 2, 2, 3, 5, 17]
+    seqs = [rng.standard_normal((ln, 13)).astype(np.float32) for ln in lens]
+    frames = np.concatenate(seqs)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    want = oracle.align_all(frames, offsets, 1.0, workers=2)
+    got = gpu_align_all(ctx, frames, offsets, 13, 1.0)
+    assert_parity(got, want)
+    assert got[0, 1] == 0.0 and np.isinf(got[0, 2]) and np.isinf(got[2, 0])
+
+
+def test_empty_inputs(ctx, apd):
+    from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
+    from audio_pattern_discovery_amd.discovery import Discovery
+    w = AlignmentWorkers.new([], ctx)
+    assert w.align_all(Discovery()).size == 0
+    # a zero-length sequence underflows usize in the reference (alignments.rs:120): refused, not guessed
+    seqs = [NDSequence(np.zeros((0, 13), np.float32)), NDSequence(np.ones((4, 13), np.float32))]
+    with pytest.raises(apd.ApdError) as e:
+        AlignmentWorkers.new(seqs, ctx).align_all(Discovery())
+    assert e.value.status == apd.APD_ERR_EMPTY_SEQUENCE
+
+
+def test_single_pair_api_matches_oracle(ctx, oracle):
+    from audio_pattern_discovery_amd.alignments import Alignment, AlignmentParams
+    rng = np.random.default_rng(3)
+    for n, m, band in [(40, 47, 5), (64, 64, 64), (3, 2, 10), (1, 1, 0), (1, 5, 3), (90, 30, 4)]:
+        x = rng.standard_normal((n, 13)).astype(np.float32)
+        y = rng.standard_normal((m, 13)).astype(np.float32)
+        a = Alignment(ctx)
+        a.construct_alignment(x, y, AlignmentParams(band, 0.8, 1.2, 1.0))
+        want = oracle.dtw_pair(x, y, band, 0.8, 1.2, 1.0)
+        assert_parity(np.array([a.score()]), np.array([want]))
+    assert Alignment(ctx).score() == float("inf")       # Alignment::new().score(), alignments.rs:117-118
+
+
+def test_kat_through_the_gpu(ctx):
+    from audio_pattern_discovery_amd.alignments import Alignment, AlignmentParams
+    a = Alignment(ctx)
+    a.construct_alignment(np.array([[0], [1], [5]], np.float32), np.array([[0], [9]], np.float32), AlignmentParams.default(3))
+    assert a.score() == pytest.approx(0.2, rel=1e-6)   # SURVEY.md §4 KAT: cell (n-1, m-1), not (n, m)
+
+
+def test_sharded_tiles_equal_single_launch(ctx, apd, oracle):
+    """world=3 slabs computed one after the other on one GPU, concatenated as an all-gather would,
+    then unpacked, must equal the single-launch matrix (the multi-GPU data path minus RCCL)."""
+    import torch
+    from audio_pattern_discovery_amd.alignments import Batch
+    from audio_pattern_discovery_amd.discovery import Discovery
+    frames, offsets = synth.make_sequences(70, 60, 13, seed=4)
+    cfg = Discovery(warping_band_percentage=0.0625).align_config()
+    L = apd.lib()
+    batch = Batch(ctx, frames, offsets, 13)
+    n, world = 70, 3
+    slab = int(L.apd_slab_floats(n, world))
+    gathered = torch.zeros(world * slab, dtype=torch.float32, device="cuda")
+    for r in range(world):
+        apd.check(L.apd_align_tiles_async(ctx.handle, batch.handle, C.byref(cfg), r, world,
+                                          C.c_void_p(gathered.data_ptr() + 4 * r * slab)), ctx.handle)
+    out = torch.empty(n * n, dtype=torch.float32, device="cuda")
+    apd.check(L.apd_unpack_tiles_async(ctx.handle, n, world, C.c_void_p(gathered.data_ptr()), C.c_void_p(out.data_ptr())),
+              ctx.handle)
+    ctx.synchronize()
+    assert_parity(out.cpu().numpy().reshape(n, n), oracle.align_all(frames, offsets, 0.0625, workers=8))
+
+
+def test_full_size_properties_cfg2(ctx, oracle):
+    """BASELINE cfg 2 shape (1024 x len~512, band 32) is too big for the oracle in full: check
+    size-independent properties + a random sample of entries against the oracle."""
+    frames, offsets = synth.make_sequences(1024, 512, 13, seed=2)
+    got = gpu_align_all(ctx, frames, offsets, 13, 0.0625)
+    assert np.all(np.diag(got) == 0.0)
+    off = ~np.eye(1024, dtype=bool)
+    assert np.all(np.isfinite(got[off])) and np.all(got[off] > 0)
+    rng = np.random.default_rng(0)
+    pi = rng.integers(0, 1024, 600).astype(np.uint32)
+    pj = rng.integers(0, 1024, 600).astype(np.uint32)
+    keep = pi != pj
+    want, _ = oracle.align_sample(frames, offsets, pi[keep], pj[keep], 0.0625, workers=8)
+    assert_parity(got[pi[keep], pj[keep]], want)
+    # identical sequences score exactly 0: duplicate one sequence and re-run a small batch
+    seqs = synth.split(frames, offsets)[:8]
+    seqs.append(seqs[3].copy())
+    f2 = np.concatenate(seqs)
+    o2 = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint64)
+    g2 = gpu_align_all(ctx, f2, o2, 13, 0.0625)
+    assert g2[3, 8] == 0.0 and g2[8, 3] == 0.0
