@@ -198,14 +198,14 @@ extern "C" int apd_batch_create(apd_context *ctx, const float *frames, const uin
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint64_t total = offsets[n_seq];
     if (total > 0 && !frames) return APD_ERR_INVALID_ARG;
-    if (total >= (1ull << 32) || offsets[0] != 0) return APD_ERR_INVALID_ARG;
+    if (total + n_seq >= (1ull << 32) || offsets[0] != 0) return APD_ERR_INVALID_ARG;
     apd_batch *b = new (std::nothrow) apd_batch();
     if (!b) return APD_ERR_OOM;
     b->ctx = ctx; b->n_seq = n_seq; b->dim = dim; b->dpad = (dim + 3) & ~3u; b->total_frames = total;
     b->offsets.assign(offsets, offsets + n_seq + 1);
     b->min_len = 0xFFFFFFFFu; b->max_len = 0;
     std::vector<uint32_t> off32(n_seq + 1);
-    for (uint32_t s = 0; s <= n_seq; ++s) off32[s] = (uint32_t)offsets[s];
+    for (uint32_t s = 0; s <= n_seq; ++s) off32[s] = (uint32_t)offsets[s] + s;   // one sentinel frame behind every sequence
     for (uint32_t s = 0; s < n_seq; ++s) {
         if (offsets[s + 1] < offsets[s]) { delete b; return APD_ERR_INVALID_ARG; }
         const uint32_t len = (uint32_t)(offsets[s + 1] - offsets[s]);
@@ -214,16 +214,18 @@ extern "C" int apd_batch_create(apd_context *ctx, const float *frames, const uin
     }
     if (n_seq == 0) b->min_len = 0;
     auto fail = [&](int rc) { apd_batch_destroy(b); return rc; };
-    const size_t padded_bytes = std::max<size_t>((size_t)total * b->dpad * sizeof(float), 16);
+    const uint64_t padded_frames = total + n_seq;
+    const size_t padded_bytes = std::max<size_t>((size_t)padded_frames * b->dpad * sizeof(float), 16);
+    b->frames_bytes = padded_bytes < 0xFFFFFE00ull ? (uint32_t)padded_bytes : 0u;
     if (hipMalloc((void **)&b->d_frames, padded_bytes) != hipSuccess) return fail(APD_ERR_OOM);
     if (hipMalloc((void **)&b->d_seq_off, (n_seq + 1) * sizeof(uint32_t)) != hipSuccess) return fail(APD_ERR_OOM);
     if (hipMemcpyAsync(b->d_seq_off, off32.data(), (n_seq + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         return fail(APD_ERR_HIP);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(APD_ERR_HIP);    // off32 is a stack-lifetime buffer
-    if (total > 0) {
+    if (padded_frames > 0) {
         const float *d_src = frames;
         float *d_tmp = nullptr;
-        if (!frames_on_device) {
+        if (!frames_on_device && total > 0) {
             if (hipMalloc((void **)&d_tmp, (size_t)total * dim * sizeof(float)) != hipSuccess) return fail(APD_ERR_OOM);
             if (hipMemcpyAsync(d_tmp, frames, (size_t)total * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
                 hipFree(d_tmp);
@@ -231,7 +233,7 @@ extern "C" int apd_batch_create(apd_context *ctx, const float *frames, const uin
             }
             d_src = d_tmp;
         }
-        hipError_t e = launch_pad(d_src, b->d_frames, total, dim, b->dpad, ctx->stream);
+        hipError_t e = launch_pad(d_src, b->d_frames, b->d_seq_off, n_seq, padded_frames, dim, b->dpad, ctx->stream);
         if (d_tmp) { hipStreamSynchronize(ctx->stream); hipFree(d_tmp); }
         if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return fail(APD_ERR_HIP); }
     }
@@ -301,7 +303,7 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
         }
     }
     AlignLaunch L{};
-    L.d_frames = batch->d_frames; L.d_seq_off = batch->d_seq_off; L.d_tiles = entry.first; L.n_tiles = entry.second;
+    L.d_frames = batch->d_frames; L.frames_bytes = batch->frames_bytes; L.d_seq_off = batch->d_seq_off; L.d_tiles = entry.first; L.n_tiles = entry.second;
     L.n_seq = batch->n_seq; L.dim = batch->dim; L.dpad = batch->dpad; L.band = band; L.d_slab = d_slab;
     L.variant = ctx->variant;
     // upper bound of w over all pairs: the band is monotone in max(n,m), the gap is at most max_len - min_len

@@ -26,8 +26,9 @@ struct BandSpec {
 
 // One launch of the fused-pair alignment over a list of tiles.
 struct AlignLaunch {
-    const float *d_frames;       // [total_frames][dpad] zero padded
-    const uint32_t *d_seq_off;   // [n_seq+1] frame offsets
+    const float *d_frames;       // [total_frames + n_seq][dpad]: zero padded dims, one +INF sentinel frame behind every sequence
+    uint32_t frames_bytes;       // size of d_frames in bytes (0 if >= 4 GiB: buffer addressing unavailable)
+    const uint32_t *d_seq_off;   // [n_seq+1] padded frame offsets (sequence s owns seq_off[s+1]-seq_off[s]-1 real frames)
     const uint2 *d_tiles;        // [n_tiles] (tile_a, tile_b), tile_a <= tile_b
     uint32_t n_tiles;
     uint32_t n_seq;
@@ -39,8 +40,8 @@ struct AlignLaunch {
 };
 
 hipError_t launch_align(const AlignLaunch &L, hipStream_t stream, std::string &err, int *status);
-hipError_t launch_pad(const float *d_src, float *d_dst, uint64_t n_frames, uint32_t dim, uint32_t dpad,
-                      hipStream_t stream);
+hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_off, uint32_t n_seq, uint64_t n_frames_padded,
+                      uint32_t dim, uint32_t dpad, hipStream_t stream);
 hipError_t launch_unpack(const float *d_gathered, float *d_out, uint32_t n_seq, uint32_t world,
                          uint64_t slab_floats, hipStream_t stream);
 hipError_t launch_selftest(int *d_result, hipStream_t stream);
@@ -82,7 +83,8 @@ struct apd_batch {
     apd_context *ctx = nullptr;
     uint32_t n_seq = 0, dim = 0, dpad = 0;
     uint64_t total_frames = 0;
-    float *d_frames = nullptr;        // padded
+    float *d_frames = nullptr;        // padded layout with sentinels (see dtw_generic.hip)
+    uint32_t frames_bytes = 0;
     uint32_t *d_seq_off = nullptr;
     std::vector<uint64_t> offsets;    // host copy
     uint32_t min_len = 0, max_len = 0;

@@ -1,0 +1,118 @@
+// Device helpers shared by the alignment kernels (gfx950).
+#pragma once
+#include "apd_internal.h"
+
+namespace apd {
+
+#define APD_INF __builtin_inff()
+
+// DPP controls (LLVM AMDGPU): row_shl:1 0x101, row_shr:1 0x111, wave_shl:1 0x130, wave_shr:1 0x138.
+// "shr" moves data towards higher lanes: lane l reads lane l-1.  A lane without a source keeps `fill`.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v, float fill)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v),
+                                                                 CTRL, 0xf, 0xf, false));
+}
+// whole-wave shifts (G = 64)
+__device__ __forceinline__ float from_lower_lane(float v, float fill) { return dpp_move<0x138>(v, fill); }
+__device__ __forceinline__ float from_upper_lane(float v, float fill) { return dpp_move<0x130>(v, fill); }
+
+// Shifts inside groups of G lanes: lane 0 of a group (no lower neighbour) / lane G-1 (no upper) gets `fill`.
+// G = 16 maps onto DPP rows; G = 64 onto the wave shifts; other sizes fix the group edges with a select.
+template <int G>
+__device__ __forceinline__ float group_from_lower(float v, float fill, int gl)
+{
+    if (G == 64) return dpp_move<0x138>(v, fill);
+    if (G == 16) return dpp_move<0x111>(v, fill);
+    const float t = dpp_move<0x138>(v, fill);
+    return gl == 0 ? fill : t;
+}
+template <int G>
+__device__ __forceinline__ float group_from_upper(float v, float fill, int gl)
+{
+    if (G == 64) return dpp_move<0x130>(v, fill);
+    if (G == 16) return dpp_move<0x101>(v, fill);
+    const float t = dpp_move<0x130>(v, fill);
+    return gl == G - 1 ? fill : t;
+}
+
+__device__ __forceinline__ uint32_t band_from_pct(float pct, uint32_t len)
+{
+    float p = pct * (float)len;                 // discovery.rs:40, one f32 rounding
+    if (!(p > 0.0f)) return 0u;                 // Rust `as usize` saturates: NaN and negatives -> 0
+    if (p >= 4294967040.0f) return 0xFFFFFFFFu;
+    return (uint32_t)p;
+}
+
+__device__ __forceinline__ int pair_w(const BandSpec &b, int n, int m)
+{
+    uint32_t mx = (uint32_t)max(n, m), gap = (uint32_t)abs(n - m);
+    uint32_t band = b.use_explicit ? b.explicit_band : band_from_pct(b.pct, mx);
+    band = min(band, mx);                       // any band >= max(n,m) already spans the whole matrix
+    return (int)(max(band, gap) + 2u);          // alignments.rs:173
+}
+
+// alignments.rs:153-159.  del_v / ins_v are the DELETE / INSERT predecessors, m_v the MATCH one.
+// Ties and NaN fall through to MATCH exactly as the two strict comparisons of the source do.
+template <bool UNIFORM_PEN>
+__device__ __forceinline__ float select_node(float del_v, float ins_v, float m_v, float d, float del_pen, float ins_pen,
+                                             float mat_pen)
+{
+    const bool pick_d = (del_v < m_v) & (del_v < ins_v);
+    const bool pick_i = (ins_v < m_v) & (ins_v < del_v);
+    float base = pick_i ? ins_v : m_v;
+    base = pick_d ? del_v : base;
+    if (UNIFORM_PEN) return __builtin_fmaf(mat_pen, d, base);
+    float pen = pick_i ? ins_pen : mat_pen;
+    pen = pick_d ? del_pen : pen;
+    return __builtin_fmaf(pen, d, base);
+}
+
+// One unordered pair (a < b) of a tile.  Frames of sequence s live at d_frames[(seq_off[s] + t) * dpad], t in
+// [0, len), followed by ONE sentinel frame of +INF (index len) used for columns j <= 0.
+struct PairInfo {
+    const float *A, *B;
+    int n, m, w;
+    int slot_a, slot_b;
+    bool valid;
+};
+
+__device__ __forceinline__ PairInfo decode_pair(const AlignLaunch &L, uint32_t tile, uint32_t slot)
+{
+    PairInfo p;
+    p.slot_a = slot / kTile;
+    p.slot_b = slot % kTile;
+    p.valid = false;
+    p.A = p.B = L.d_frames; p.n = p.m = 2; p.w = 2;
+    if (tile >= L.n_tiles) return p;
+    const uint2 t = L.d_tiles[tile];
+    const uint32_t a = t.x * kTile + p.slot_a, b = t.y * kTile + p.slot_b;
+    if (!((a < b) && (b < L.n_seq))) return p;
+    p.valid = true;
+    const uint32_t oa = L.d_seq_off[a], ob = L.d_seq_off[b];
+    p.n = (int)(L.d_seq_off[a + 1] - oa) - 1;
+    p.m = (int)(L.d_seq_off[b + 1] - ob) - 1;
+    p.A = L.d_frames + (uint64_t)oa * L.dpad;
+    p.B = L.d_frames + (uint64_t)ob * L.dpad;
+    p.w = pair_w(L.band, p.n, p.m);
+    return p;
+}
+
+__device__ __forceinline__ void store_pair(const AlignLaunch &L, uint32_t tile, const PairInfo &p, float s1, float s2)
+{
+    float *slab = L.d_slab + (uint64_t)tile * 2 * kSlotsPerTile;
+    slab[p.slot_a * kTile + p.slot_b] = s1;                       // score(x=a, y=b)
+    slab[kSlotsPerTile + p.slot_a * kTile + p.slot_b] = s2;       // score(x=b, y=a)
+}
+
+// Host launchers of the templated systolic kernel, one translation unit per frame dimension.
+// Returns false when (G, C) is not instantiated.
+template <int D>
+bool launch_systolic(const AlignLaunch &L, int g, int c, bool uniform_pen, hipStream_t stream);
+extern template bool launch_systolic<8>(const AlignLaunch &, int, int, bool, hipStream_t);
+extern template bool launch_systolic<10>(const AlignLaunch &, int, int, bool, hipStream_t);
+extern template bool launch_systolic<13>(const AlignLaunch &, int, int, bool, hipStream_t);
+extern template bool launch_systolic<26>(const AlignLaunch &, int, int, bool, hipStream_t);
+
+}  // namespace apd

@@ -1,0 +1,241 @@
+// Generic fused-pair banded DTW + layout/unpack helpers + kernel dispatch (gfx950).
+//
+// Replaces the per-pair body of AlignmentWorkers::align_all (reference src/alignments.rs:50-58):
+// Alignment::new + construct_alignment (:165-180) + alignment_score (:129-160) + score (:116-125).
+//
+// Work unit: one UNORDERED pair (a, b), a < b.  One sweep computes BOTH ordered scores
+//   DP1 = score(x = a, y = b)  and  DP2 = score(x = b, y = a),
+// because the two recurrences visit (almost) the same cells and share every local distance
+// euclidean(A[i], B[j]) (numerics.rs:114-120).  In A-row / B-column coordinates (i over A, j over B, band
+// offset o = j - i, u = o + w):
+//   DP1: u in [0, 2w-1], left neighbour (i, j-1) is the DELETE branch, up (i-1, j) the INSERT branch;
+//   DP2: u in [1, 2w],   up   neighbour is the DELETE branch, left the INSERT branch
+// (DP2's cell (j, i) of the swapped problem is our cell (i, j); the reference band j'-i' in [-w, w-1] of
+// alignments.rs:175 becomes o in [-w+1, w]).  Each DP is exactly the reference recurrence for its ordered pair.
+//
+// Lane mapping: a lane owns C consecutive offsets u = C*l + c.  Macro-step tau: every lane processes row
+// i = tau - l, its C cells left to right.  Dependences across lanes:
+//   (i, u-1) of the first cell  = last cell of lane l-1 from the PREVIOUS macro-step  -> DPP shift up
+//   (i-1, u+1) of the last cell = first cell of lane l+1 from THIS macro-step          -> DPP shift down
+// so C >= 2 and the min(INS, DEL, MATCH) dependency never goes through memory.
+// Only rows 1..n-1 and columns 1..m-1 are swept: score() reads cell (n-1, m-1) (alignments.rs:120); row n and
+// column m never influence it.
+//
+// The kernel in this file is the slow, fully general one: any frame dimension, any band up to what 160 KB of LDS
+// holds (C chosen at run time, per-lane DP rows in LDS, every boundary tested per cell, any penalty values).
+// dtw_systolic.h holds the production kernel.
+#include "dtw_common.h"
+
+namespace apd {
+
+__global__ __launch_bounds__(64) void dtw_fused_generic(const AlignLaunch L, int c_max)
+{
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x;
+    const uint32_t wave = blockIdx.x;
+    const uint32_t tile = wave / kSlotsPerTile, slot = wave % kSlotsPerTile;
+    const PairInfo P = decode_pair(L, tile, slot);
+    if (!P.valid) return;
+    const int n = P.n, m = P.m, w = P.w;
+    if (n == 1 || m == 1) {                                   // alignments.rs:116-125 with an absent cell
+        if (lane == 0) { const float s = (n == 1 && m == 1) ? 0.0f : APD_INF; store_pair(L, tile, P, s, s); }
+        return;
+    }
+    const float ins = L.band.ins, del = L.band.del, mat = L.band.mat;
+    const int two_w = 2 * w;
+    int C = (two_w + 1 + 63) / 64;
+    C = max(C, 2);
+    float *p1 = lds, *p2 = lds + c_max * 64;               // [c][lane]
+    for (int c = 0; c < C; ++c) { p1[c * 64 + lane] = APD_INF; p2[c * 64 + lane] = APD_INF; }
+    const int dp4 = (int)L.dpad / 4;
+    const int u0 = C * lane;
+    const int g_act = (two_w + 1 + C - 1) / C;
+    const int total = (n - 1) + g_act;
+    float res1 = 0.0f, res2 = 0.0f;
+    float last1 = APD_INF, last2 = APD_INF;
+    for (int tau = 0; tau < total; ++tau) {
+        const int i = tau - lane;
+        const int jb = i + u0 - w;
+        const float4 *xa = reinterpret_cast<const float4 *>(P.A + (uint64_t)(min(max(i, 1), n) - 1) * L.dpad);
+        float left1 = from_lower_lane(last1, APD_INF);
+        float left2 = from_lower_lane(last2, APD_INF);
+        float upr1 = APD_INF, upr2 = APD_INF;
+        float nxt1 = p1[lane], nxt2 = p2[lane];             // prev[c] for c = 0
+        for (int c = 0; c < C; ++c) {
+            const int j = jb + c, u = u0 + c;
+            const float4 *yb = reinterpret_cast<const float4 *>(P.B + (uint64_t)(min(max(j, 1), m) - 1) * L.dpad);
+            float acc = 0.0f;
+            for (int q = 0; q < dp4; ++q) {                  // zero padded dims add exactly 0
+                const float4 xv = xa[q], yv = yb[q];
+                float t = xv.x - yv.x;
+                acc = (q == 0) ? t * t : __builtin_fmaf(t, t, acc);
+                t = xv.y - yv.y; acc = __builtin_fmaf(t, t, acc);
+                t = xv.z - yv.z; acc = __builtin_fmaf(t, t, acc);
+                t = xv.w - yv.w; acc = __builtin_fmaf(t, t, acc);
+            }
+            const float d = __builtin_amdgcn_sqrtf(acc);
+            const float m1 = nxt1, m2 = nxt2;
+            float up1, up2;
+            if (c < C - 1) { up1 = p1[(c + 1) * 64 + lane]; up2 = p2[(c + 1) * 64 + lane]; }
+            else { up1 = upr1; up2 = upr2; }
+            nxt1 = up1; nxt2 = up2;                          // prev[c+1] is the next cell's MATCH predecessor
+            float r1 = select_node<false>(left1, up1, m1, d, del, ins, mat);   // DP1: left = DELETE, up = INSERT
+            float r2 = select_node<false>(up2, left2, m2, d, del, ins, mat);   // DP2: up = DELETE, left = INSERT
+            const bool inside = (i >= 1) & (j >= 1);
+            const float inv = ((i == 0) & (j == 0)) ? 0.0f : APD_INF;          // D[0][0] = 0 (alignments.rs:109)
+            r1 = (inside & (u <= two_w - 1)) ? r1 : inv;
+            r2 = (inside & (u >= 1) & (u <= two_w)) ? r2 : inv;
+            if ((i == n - 1) & (j == m - 1)) { res1 = r1; res2 = r2; }
+            p1[c * 64 + lane] = r1; p2[c * 64 + lane] = r2;
+            left1 = r1; left2 = r2;
+            if (c == 0) { upr1 = from_upper_lane(r1, APD_INF); upr2 = from_upper_lane(r2, APD_INF); }
+        }
+        last1 = left1; last2 = left2;
+    }
+    const int ustar = (m - 1) - (n - 1) + w;
+    if (lane == ustar / C) {
+        const float denom = (float)(n + m);                  // alignments.rs:121
+        store_pair(L, tile, P, res1 / denom, res2 / denom);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Resident layout: [frames of seq 0 | +INF sentinel | frames of seq 1 | +INF sentinel | ...], every frame
+// padded to dpad floats (zeros).  seq_off[s] = offsets[s] + s.
+// ------------------------------------------------------------------------------------------------
+__global__ void pad_frames_kernel(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ seq_off,
+                                  uint32_t n_seq, uint64_t n_frames_padded, uint32_t dim, uint32_t dpad)
+{
+    const uint64_t total = n_frames_padded * dpad;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t f = (uint32_t)(e / dpad);
+        const uint32_t k = (uint32_t)(e - (uint64_t)f * dpad);
+        uint32_t lo = 0, hi = n_seq;                          // largest s with seq_off[s] <= f
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seq_off[mid] <= f) lo = mid; else hi = mid; }
+        const bool sentinel = (f + 1 == seq_off[lo + 1]);
+        float v = 0.0f;
+        if (k < dim) v = sentinel ? APD_INF : src[(uint64_t)(f - lo) * dim + k];
+        dst[e] = v;
+    }
+}
+
+// gathered: `world` slabs of slab_floats each; slab r holds tiles r, r+world, ... in order.
+__global__ void unpack_tiles_kernel(const float *__restrict__ gathered, float *__restrict__ out, uint32_t n_seq,
+                                    uint32_t world, uint64_t slab_floats, uint32_t n_tiles_side)
+{
+    const uint32_t g = blockIdx.x;                            // (ta, tb), ta <= tb, row-major over the upper triangle
+    uint32_t ta = 0, rem = g, row = n_tiles_side;
+    while (rem >= row) { rem -= row; ++ta; --row; }
+    const uint32_t tb = ta + rem;
+    const uint32_t rank = g % world, local = g / world;
+    const float *slab = gathered + (uint64_t)rank * slab_floats + (uint64_t)local * 2 * kSlotsPerTile;
+    const int sa = threadIdx.x / kTile, sb = threadIdx.x % kTile;
+    const uint32_t a = ta * kTile + sa, b = tb * kTile + sb;
+    if (a < b && b < n_seq) {
+        out[(uint64_t)a * n_seq + b] = slab[sa * kTile + sb];
+        out[(uint64_t)b * n_seq + a] = slab[kSlotsPerTile + sa * kTile + sb];
+    }
+}
+
+__global__ void selftest_kernel(int *result)
+{
+    const int lane = threadIdx.x;
+    const float v = (float)lane;
+    bool ok = true;
+    ok &= from_lower_lane(v, -1.0f) == (lane == 0 ? -1.0f : (float)(lane - 1));
+    ok &= from_upper_lane(v, -2.0f) == (lane == 63 ? -2.0f : (float)(lane + 1));
+    ok &= group_from_lower<16>(v, -3.0f, lane % 16) == (lane % 16 == 0 ? -3.0f : (float)(lane - 1));
+    ok &= group_from_upper<16>(v, -4.0f, lane % 16) == (lane % 16 == 15 ? -4.0f : (float)(lane + 1));
+    ok &= group_from_lower<32>(v, -5.0f, lane % 32) == (lane % 32 == 0 ? -5.0f : (float)(lane - 1));
+    ok &= group_from_upper<8>(v, -6.0f, lane % 8) == (lane % 8 == 7 ? -6.0f : (float)(lane + 1));
+    const unsigned long long all = __ballot(ok);
+    if (lane == 0) *result = (all == ~0ull) ? 1 : 0;
+}
+
+hipError_t launch_selftest(int *d_result, hipStream_t stream)
+{
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, stream, d_result);
+    return hipGetLastError();
+}
+
+hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_off, uint32_t n_seq, uint64_t n_frames_padded,
+                      uint32_t dim, uint32_t dpad, hipStream_t stream)
+{
+    if (n_frames_padded == 0) return hipSuccess;
+    const uint64_t total = n_frames_padded * dpad;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 16384);
+    hipLaunchKernelGGL(pad_frames_kernel, dim3(blocks), dim3(256), 0, stream, d_src, d_dst, d_seq_off, n_seq, n_frames_padded,
+                       dim, dpad);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack(const float *d_gathered, float *d_out, uint32_t n_seq, uint32_t world, uint64_t slab_floats,
+                         hipStream_t stream)
+{
+    const uint32_t side = (n_seq + kTile - 1) / kTile;
+    const uint64_t n_tiles = (uint64_t)side * (side + 1) / 2;
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_tiles_kernel, dim3((uint32_t)n_tiles), dim3(kSlotsPerTile), 0, stream, d_gathered, d_out,
+                       n_seq, world, slab_floats, side);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// dispatch
+// ------------------------------------------------------------------------------------------------
+struct Geometry { int g, c; };
+
+// Pick the (lanes per pair, offsets per lane) that wastes the fewest lanes for a band of `need` offsets.
+static Geometry pick_geometry(uint32_t need)
+{
+    static const Geometry all[] = {{16, 2}, {16, 3}, {16, 5}, {16, 9}, {64, 3}, {64, 5}, {64, 9}};
+    Geometry best{0, 0};
+    double best_util = 0.0;
+    for (const Geometry &q : all) {
+        if ((uint32_t)(q.g * q.c) < need) continue;
+        const double util = (double)need / (double)(q.g * q.c) - 0.004 * (9 - q.c);   // larger C: fewer exchanges per cell
+        if (util > best_util) { best_util = util; best = q; }
+    }
+    return best;
+}
+
+hipError_t launch_align(const AlignLaunch &L, hipStream_t stream, std::string &err, int *status)
+{
+    *status = APD_OK;
+    if (L.n_tiles == 0) return hipSuccess;
+    const BandSpec &b = L.band;
+    const bool uniform = (b.ins == b.del) && (b.del == b.mat);
+    // the systolic kernel turns boundary cells into +INF through pen * INF: needs finite penalties > 0
+    const bool pens_ok = (b.ins > 0.0f) && (b.del > 0.0f) && (b.mat > 0.0f) && (b.ins < APD_INF) && (b.del < APD_INF) &&
+                         (b.mat < APD_INF);
+    bool done = false;
+    if (L.variant != 1 && pens_ok && L.frames_bytes != 0) {
+        Geometry q = pick_geometry(2 * L.w_max + 1);
+        if (L.variant >= 100) { q.g = L.variant / 100; q.c = L.variant % 100; if ((uint32_t)(q.g * q.c) < 2 * L.w_max + 1) q.g = 0; }
+        if (q.g != 0) {
+            switch (L.dim) {
+                case 8: done = launch_systolic<8>(L, q.g, q.c, uniform, stream); break;
+                case 10: done = launch_systolic<10>(L, q.g, q.c, uniform, stream); break;
+                case 13: done = launch_systolic<13>(L, q.g, q.c, uniform, stream); break;
+                case 26: done = launch_systolic<26>(L, q.g, q.c, uniform, stream); break;
+                default: break;
+            }
+        }
+    }
+    if (!done) {
+        int c_max = (int)((2 * (uint64_t)L.w_max + 1 + 63) / 64);
+        if (c_max < 2) c_max = 2;
+        const size_t lds_bytes = (size_t)c_max * 64 * 2 * sizeof(float);
+        if (lds_bytes > 160 * 1024) { *status = APD_ERR_BAND_TOO_WIDE; err = "band too wide for the generic kernel"; return hipSuccess; }
+        if (lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_fused_generic),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        const uint64_t waves = (uint64_t)L.n_tiles * kSlotsPerTile;
+        hipLaunchKernelGGL(dtw_fused_generic, dim3((uint32_t)waves), dim3(64), lds_bytes, stream, L, c_max);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace apd

@@ -1,0 +1,5 @@
+// Instantiates the systolic fused-pair DTW kernel for frame dimension 13 (one unit per D so they build in parallel).
+#include "dtw_systolic.h"
+namespace apd {
+template bool launch_systolic<13>(const AlignLaunch &, int, int, bool, hipStream_t);
+}
