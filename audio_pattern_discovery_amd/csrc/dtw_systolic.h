@@ -38,6 +38,16 @@ __device__ __forceinline__ void load_frame(float (&dst)[D], __amdgpu_buffer_rsrc
     }
 }
 
+// Same, one dword per instruction: no register-tuple constraint on the destination, so a frame can be fetched in
+// place into registers that the DPP shifts also write (the allocator then needs no copies on the loop back-edge).
+template <int D>
+__device__ __forceinline__ void load_frame_dwords(float (&dst)[D], __amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off)
+{
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+        dst[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_off + 4u * k, 0, 0));
+}
+
 // numerics.rs:114-120 as an fma chain, k ascending; v_sqrt_f32 (<= 1 ulp).
 template <int D>
 __device__ __forceinline__ float frame_dist(const float (&x)[D], const float (&y)[D])
@@ -103,52 +113,66 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
         total = max(total, __builtin_amdgcn_readlane(my_total, g * G));
         min_rows = min(min_rows, __builtin_amdgcn_readlane(my_min, g * G));
     }
-    const int total_r = ((total + C - 1) / C) * C;
-    const int a_end = min(((G + C - 1) / C) * C, total_r);
-    const int b_end = min(max((min_rows / C) * C, a_end), total_r);
+    // Column window: S = C + 1 register slots used as a ring (slot = column mod S): C live columns plus the one
+    // entering at the next macro-step.  Row frames: two sets, ping-pong.  With the loop unrolled U = lcm(S, 2)
+    // macro-steps every slot keeps its physical registers (no copies on the back-edge).
+    constexpr int S = C + 1;
+    constexpr int U = (S % 2 == 0) ? S : 2 * S;
+    const int total_r = ((total + U - 1) / U) * U;
+    const int a_end = min(((G + U - 1) / U) * U, total_r);
+    const int b_end = min(max((min_rows / U) * U, a_end), total_r);
 
     float prev1[C], prev2[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) { prev1[c] = APD_INF; prev2[c] = APD_INF; }
     float res1 = 0.0f, res2 = 0.0f;
 
-    // column window at macro-step 0: j = -gl + u0 + c - w; columns <= 0 read the +INF sentinel (index m)
-    float yf[C][D];
+    // window at macro-step 0: column j = -gl + u0 + c - w in slot c; columns <= 0 read the +INF sentinel (index m)
+    float yf[S][D];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const int j = u0 - gl + c - w;
         const int idx = (j >= 1) ? (min(j, m) - 1) : m;
         load_frame<D>(yf[c], rsrc, b_off + (uint32_t)idx * FB);
     }
-    float xr[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) xr[k] = -APD_INF;             // rows <= 0
+    for (int k = 0; k < D; ++k) yf[C][k] = 0.0f;
+    float xs[2][D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) { xs[0][k] = -APD_INF; xs[1][k] = -APD_INF; }   // rows <= 0
 
     auto macro_steps = [&](int tau_begin, int tau_end, auto slow_tag) {
         constexpr bool SLOW = decltype(slow_tag)::value;
-        for (int tau0 = tau_begin; tau0 < tau_end; tau0 += C) {
+        for (int tau0 = tau_begin; tau0 < tau_end; tau0 += U) {
 #pragma unroll
-            for (int r = 0; r < C; ++r) {
-                const int tau = tau0 + r;
-                // frames entering the group at the next macro-step, fetched by the two edge lanes
-                float xin[D], yin[D];
+            for (int q = 0; q < U; ++q) {
+                const int tau = tau0 + q;
+                const int r = q % S;               // slot of this step's first column
+                const int xa = q & 1, xb = xa ^ 1; // current / next row-frame set
+                const int e = (r + C) % S;         // slot of the column entering at tau + 1 (dead during this step)
+                // frames entering the group at tau + 1: fetched by the two edge lanes straight into the dead
+                // registers (other lanes' offsets are out of range: no memory access, and the DPP below overwrites them)
                 {
                     const uint32_t xo = a_off + (uint32_t)(min(tau + 1, n) - 1) * FB;
                     const int jt = tau + 1 + (C - 1) * G - w;
                     const uint32_t yo = b_off + (uint32_t)((jt >= 1) ? (min(jt, m) - 1) : m) * FB;
-                    load_frame<D>(xin, rsrc, gl == 0 ? xo : kNoFrame);
-                    load_frame<D>(yin, rsrc, gl == G - 1 ? yo : kNoFrame);
+                    load_frame<D>(xs[xb], rsrc, gl == 0 ? xo : kNoFrame);
+                    load_frame<D>(yf[e], rsrc, gl == G - 1 ? yo : kNoFrame);
                 }
+                // the C local distances of this row
+                float d[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) d[c] = frame_dist<D>(xs[xa], yf[(r + c) % S]);
+                // the two DP rows
                 float left1 = group_from_lower<G>(prev1[C - 1], APD_INF, gl);
                 float left2 = group_from_lower<G>(prev2[C - 1], APD_INF, gl);
                 float upr1 = APD_INF, upr2 = APD_INF;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    const float d = frame_dist<D>(xr, yf[(r + c) % C]);
                     const float up1 = (c < C - 1) ? prev1[(c + 1) % C] : upr1;
                     const float up2 = (c < C - 1) ? prev2[(c + 1) % C] : upr2;
-                    float r1 = select_node<UNIFORM_PEN>(left1, up1, prev1[c], d, del, ins, mat);   // left = DELETE
-                    float r2 = select_node<UNIFORM_PEN>(up2, left2, prev2[c], d, del, ins, mat);   // up   = DELETE
+                    float r1 = select_node<UNIFORM_PEN>(left1, up1, prev1[c], d[c], del, ins, mat);   // left = DELETE
+                    float r2 = select_node<UNIFORM_PEN>(up2, left2, prev2[c], d[c], del, ins, mat);   // up   = DELETE
                     r1 = g1[c] ? APD_INF : r1;
                     r2 = g2[c] ? APD_INF : r2;
                     prev1[c] = r1; prev2[c] = r2;
@@ -168,18 +192,11 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                         for (int c = 0; c < C; ++c) if (c == cstar) { res1 = prev1[c]; res2 = prev2[c]; }
                     }
                 }
-                // advance the systolic pipelines for macro-step tau + 1
+                // advance both systolic pipelines: x one lane up, the column window one lane down
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
-                    xr[k] = group_from_lower<G>(xr[k], xin[k], gl);
-                    yf[r % C][k] = group_from_upper<G>(yf[(r + 1) % C][k], yin[k], gl);
-                }
-                if (G != 64 && G != 16) {                         // select-based group edges need the fill re-applied
-#pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        if (gl == 0) xr[k] = xin[k];
-                        if (gl == G - 1) yf[r % C][k] = yin[k];
-                    }
+                    xs[xb][k] = group_from_lower<G>(xs[xa][k], xs[xb][k], gl);
+                    yf[e][k] = group_from_upper<G>(yf[(r + 1) % S][k], yf[e][k], gl);
                 }
             }
         }
