@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libapd_hip.so")
+LIB_PATH = os.environ.get("APD_LIB") or os.path.join(_HERE, "libapd_hip.so")   # APD_LIB: tuning builds only
 
 APD_OK = 0
 APD_ERR_INVALID_ARG = -1

@@ -54,21 +54,23 @@ __device__ __forceinline__ int pair_w(const BandSpec &b, int n, int m)
 }
 
 // alignments.rs:153-159.  del_v / ins_v are the DELETE / INSERT predecessors, m_v the MATCH one.
-// Ties and NaN fall through to MATCH exactly as the two strict comparisons of the source do.
+// `force_match` makes the node take the MATCH branch regardless: the systolic kernel sets it on the cells just
+// outside a DP's band, whose MATCH predecessor (the same band offset one row up) is +INF by induction, so the cell
+// evaluates to +INF at the price of one scalar mask OR instead of a vector select.
 template <bool UNIFORM_PEN>
 __device__ __forceinline__ float select_node(float del_v, float ins_v, float m_v, float d, float del_pen, float ins_pen,
-                                             float mat_pen)
+                                             float mat_pen, bool force_match = false)
 {
     if (UNIFORM_PEN) {
-        // With one penalty only the predecessor matters.  DELETE is taken iff del_v < min(m_v, ins_v), INSERT iff
-        // ins_v < min(m_v, del_v), else MATCH: i.e. the smaller of (del_v, ins_v) when it is strictly below m_v and the
-        // two differ, else m_v.  Same result as the branch chain for non-NaN inputs in 4 VALU ops instead of 6.
-        const float a = __builtin_fminf(del_v, ins_v);
-        const bool take = (a < m_v) & (del_v != ins_v);
-        return __builtin_fmaf(mat_pen, d, take ? a : m_v);
+        // With one penalty only the predecessor VALUE matters.  del_v < ins_v: DELETE iff del_v < m_v, i.e. the value
+        // min(del_v, m_v); ins_v < del_v: likewise min(ins_v, m_v); del_v == ins_v: neither strict test can hold ->
+        // m_v.  So base = (del_v == ins_v) ? m_v : min3(del_v, ins_v, m_v): 3 VALU ops, no scalar mask arithmetic.
+        // (Identical to the branch chain for non-NaN inputs; NaN features are outside the supported domain.)
+        const float lo = __builtin_fminf(__builtin_fminf(del_v, ins_v), m_v);
+        return __builtin_fmaf(mat_pen, d, ((del_v == ins_v) | force_match) ? m_v : lo);
     }
-    const bool pick_d = (del_v < m_v) & (del_v < ins_v);
-    const bool pick_i = (ins_v < m_v) & (ins_v < del_v);
+    const bool pick_d = (del_v < m_v) & (del_v < ins_v) & !force_match;
+    const bool pick_i = (ins_v < m_v) & (ins_v < del_v) & !force_match;
     float base = pick_i ? ins_v : m_v;
     base = pick_d ? del_v : base;
     float pen = pick_i ? ins_pen : mat_pen;

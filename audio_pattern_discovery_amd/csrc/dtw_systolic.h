@@ -3,17 +3,25 @@
 // See dtw_generic.hip for the recurrence and the DP1/DP2 fusion.  This kernel adds:
 //  * G lanes per unordered pair (64/G pairs per wavefront), lane gl owns C band offsets u = C*gl + c, so that a
 //    band of 2w+1 offsets fills the wave instead of leaving lanes idle (w = 66 -> G = 16, C = 9: 133/144 busy);
-//  * frames never touch LDS: the row frame x[i] enters at lane 0 of a group and moves one lane up per
-//    macro-step, column frames y[j] enter at lane G-1 and move one lane down (DPP row/wave shifts), each lane
-//    keeping its C-column window in registers.  One frame of each sequence is read from memory per macro-step,
-//    by one lane: the algorithmic minimum 4*D*(n+m) bytes per ordered pair is also what the kernel fetches;
+//  * column frames y[j] enter at lane G-1 of a group and move one lane down per macro-step (DPP row/wave shifts),
+//    each lane keeping its C-column window in registers; row frames x[i] (shared by every group of the wave: the
+//    pairs of a wave have the same a) are staged once per wave in a small LDS ring, filled by coalesced 16-byte
+//    loads U rows ahead, and read back by every lane (row tau + 1 - gl).  Each frame is fetched from memory once
+//    per wave: the algorithmic minimum 4*D*(n+m) bytes per ordered pair is an upper bound of what the kernel reads;
 //  * no per-cell boundary tests: rows <= 0 use an x frame of -INF, columns <= 0 the +INF sentinel frame stored
 //    behind every sequence, so those cells evaluate to +INF by arithmetic (penalties must be > 0; otherwise the
 //    dispatcher takes the generic kernel); D[0][0] = 0 (alignments.rs:109) is injected and the result cell
 //    (n-1, m-1) (alignments.rs:120) captured only in the first G and last G macro-steps ("slow" phases);
-//  * the static band edges (DP1 stops at u = 2w-1, DP2 spans u = 1..2w) are two per-lane masks per offset.
+//  * the static band edges (DP1 stops at u = 2w-1, DP2 spans u = 1..2w) are two per-lane scalar masks per offset
+//    OR-ed into the select (see select_node): no vector instruction.
 #pragma once
 #include <type_traits>
+
+// Timing-only ablations for kernel tuning (results become wrong): build one unit with -DAPD_ABLATE=<bits>.
+//   1 no sqrt   2 no DP rows   4 no frame shifts   8 no edge fetches   16 no band guards
+#ifndef APD_ABLATE
+#define APD_ABLATE 0
+#endif
 
 #include "dtw_common.h"
 
@@ -59,6 +67,7 @@ __device__ __forceinline__ float frame_dist(const float (&x)[D], const float (&y
         t = x[k] - y[k];
         acc = __builtin_fmaf(t, t, acc);
     }
+    if (APD_ABLATE & 1) return acc;
     return __builtin_amdgcn_sqrtf(acc);
 }
 
@@ -86,7 +95,19 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)L.d_frames, 0, L.frames_bytes, 0x00020000);
     const uint32_t a_off = (uint32_t)(P.A - L.d_frames) * 4u, b_off = (uint32_t)(P.B - L.d_frames) * 4u;   // bytes
     constexpr uint32_t FB = DP * 4u;                             // bytes per padded frame
-    const float ins = L.band.ins, del = L.band.del, mat = L.band.mat;
+    float ins = L.band.ins, del = L.band.del, mat = L.band.mat;
+    asm volatile("" : "+v"(ins), "+v"(del), "+v"(mat));       // keep the penalties in VGPRs: an SGPR operand doubles the fma's issue cost
+    // row-frame ring of this wave: slot = row & (R - 1); rows <= 0 hold -INF.  R > 2U + G - 2 keeps a refill from
+    // overwriting a row some lane still needs.
+    constexpr int R = (G == 64) ? 128 : 64;
+    constexpr int LPF = DP / 4;                                  // lanes (16-byte pieces) per frame
+    constexpr int FPF = 64 / LPF;                                // frames per wave-wide fill
+    __shared__ float xring_all[4][R * DP];
+    float *const xring = xring_all[threadIdx.x >> 6];
+    // sequence a (and its length) is the same for every sweeping group of the wave
+    const int lead = __builtin_ctzll(__ballot(sweep));
+    const uint32_t a_off_w = __builtin_amdgcn_readlane(a_off, lead);
+    const int n_w = __builtin_amdgcn_readlane(n, lead);
     const int u0 = C * gl;
     const int two_w = 2 * w;
 
@@ -137,27 +158,66 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     }
 #pragma unroll
     for (int k = 0; k < D; ++k) yf[C][k] = 0.0f;
-    float xs[2][D];
+    // ring prologue: rows -(G-1)..0 are -INF, rows 1..U come from memory
+    constexpr int NFILL = (U + FPF - 1) / FPF;
+    const int fill_f = lane / LPF, fill_q = lane % LPF;          // this lane's frame and 16-byte piece inside a fill
+    auto fill_load = [&](int first_row, apd_f32x4 (&regs)[NFILL]) {
 #pragma unroll
-    for (int k = 0; k < D; ++k) { xs[0][k] = -APD_INF; xs[1][k] = -APD_INF; }   // rows <= 0
+        for (int f = 0; f < NFILL; ++f) {
+            const int fi = f * FPF + fill_f;
+            const bool act = (fill_f < FPF) & (fi < U);
+            const uint32_t off = a_off_w + (uint32_t)(min(first_row + fi, n_w) - 1) * FB + 16u * fill_q;
+            regs[f] = __builtin_bit_cast(apd_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, act ? off : kNoFrame, 0, 0));
+        }
+    };
+    auto fill_store = [&](int first_row, const apd_f32x4 (&regs)[NFILL]) {
+#pragma unroll
+        for (int f = 0; f < NFILL; ++f) {
+            const int fi = f * FPF + fill_f;
+            if ((fill_f < FPF) & (fi < U))
+                *reinterpret_cast<apd_f32x4 *>(&xring[((first_row + fi) & (R - 1)) * DP + 4 * fill_q]) = regs[f];
+        }
+    };
+    for (int e = lane; e < G * DP; e += 64) xring[((-(e / DP)) & (R - 1)) * DP + (e % DP)] = -APD_INF;
+    {
+        apd_f32x4 regs[NFILL];
+        fill_load(1, regs);
+        fill_store(1, regs);
+    }
+    auto read_row = [&](float (&dst)[D], int row) {
+        const float *p = &xring[(row & (R - 1)) * DP];
+#pragma unroll
+        for (int q = 0; q < LPF; ++q) {
+            const apd_f32x4 t = *reinterpret_cast<const apd_f32x4 *>(p + 4 * q);
+            if (4 * q + 0 < D) dst[4 * q + 0] = t.x;
+            if (4 * q + 1 < D) dst[4 * q + 1] = t.y;
+            if (4 * q + 2 < D) dst[4 * q + 2] = t.z;
+            if (4 * q + 3 < D) dst[4 * q + 3] = t.w;
+        }
+    };
+    float xs[2][D];
+    read_row(xs[0], 0 - gl);                                     // macro-step 0: row -gl (all -INF)
+#pragma unroll
+    for (int k = 0; k < D; ++k) xs[1][k] = 0.0f;
 
     auto macro_steps = [&](int tau_begin, int tau_end, auto slow_tag) {
         constexpr bool SLOW = decltype(slow_tag)::value;
         for (int tau0 = tau_begin; tau0 < tau_end; tau0 += U) {
+            apd_f32x4 fill_regs[NFILL];
+            fill_load(tau0 + U + 1, fill_regs);                  // rows of the NEXT block, stored at this block's end
 #pragma unroll
             for (int q = 0; q < U; ++q) {
                 const int tau = tau0 + q;
                 const int r = q % S;               // slot of this step's first column
                 const int xa = q & 1, xb = xa ^ 1; // current / next row-frame set
                 const int e = (r + C) % S;         // slot of the column entering at tau + 1 (dead during this step)
-                // frames entering the group at tau + 1: fetched by the two edge lanes straight into the dead
-                // registers (other lanes' offsets are out of range: no memory access, and the DPP below overwrites them)
+                // column frame entering the group at tau + 1: fetched by the top lane straight into the dead slot
+                // (other lanes' offsets are out of range: no memory access, and the DPP below overwrites them)
                 {
-                    const uint32_t xo = a_off + (uint32_t)(min(tau + 1, n) - 1) * FB;
                     const int jt = tau + 1 + (C - 1) * G - w;
                     const uint32_t yo = b_off + (uint32_t)((jt >= 1) ? (min(jt, m) - 1) : m) * FB;
-                    load_frame<D>(xs[xb], rsrc, gl == 0 ? xo : kNoFrame);
-                    load_frame<D>(yf[e], rsrc, gl == G - 1 ? yo : kNoFrame);
+                    if (!(APD_ABLATE & 8)) load_frame<D>(yf[e], rsrc, gl == G - 1 ? yo : kNoFrame);
+                    read_row(xs[xb], tau + 1 - gl);               // next row frame from the wave's LDS ring
                 }
                 // the C local distances of this row
                 float d[C];
@@ -169,12 +229,12 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                 float upr1 = APD_INF, upr2 = APD_INF;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
+                    if (APD_ABLATE & 2) { prev1[c] += d[c]; prev2[c] -= d[c]; continue; }
                     const float up1 = (c < C - 1) ? prev1[(c + 1) % C] : upr1;
                     const float up2 = (c < C - 1) ? prev2[(c + 1) % C] : upr2;
-                    float r1 = select_node<UNIFORM_PEN>(left1, up1, prev1[c], d[c], del, ins, mat);   // left = DELETE
-                    float r2 = select_node<UNIFORM_PEN>(up2, left2, prev2[c], d[c], del, ins, mat);   // up   = DELETE
-                    r1 = g1[c] ? APD_INF : r1;
-                    r2 = g2[c] ? APD_INF : r2;
+                    // guards: outside a DP's band the node is forced onto its MATCH predecessor, which is +INF
+                    const float r1 = select_node<UNIFORM_PEN>(left1, up1, prev1[c], d[c], del, ins, mat, (APD_ABLATE & 16) ? false : g1[c]);   // left = DELETE
+                    const float r2 = select_node<UNIFORM_PEN>(up2, left2, prev2[c], d[c], del, ins, mat, (APD_ABLATE & 16) ? false : g2[c]);   // up   = DELETE
                     prev1[c] = r1; prev2[c] = r2;
                     left1 = r1; left2 = r2;
                     if (c == 0) {
@@ -192,13 +252,14 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                         for (int c = 0; c < C; ++c) if (c == cstar) { res1 = prev1[c]; res2 = prev2[c]; }
                     }
                 }
-                // advance both systolic pipelines: x one lane up, the column window one lane down
+                // advance the column window: every column moves one lane down
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
-                    xs[xb][k] = group_from_lower<G>(xs[xa][k], xs[xb][k], gl);
+                    if (APD_ABLATE & 4) { yf[e][k] = yf[(r + 1) % S][k] + yf[e][k]; continue; }
                     yf[e][k] = group_from_upper<G>(yf[(r + 1) % S][k], yf[e][k], gl);
                 }
             }
+            fill_store(tau0 + U + 1, fill_regs);
         }
     };
     macro_steps(0, a_end, std::true_type{});

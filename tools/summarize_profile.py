@@ -1,0 +1,40 @@
+"""Condenses rocprofv3 CSV output (kernel trace stats + PMC passes) into a small text summary."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
+
+
+print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+for path in find("trace/**/*kernel_stats.csv"):
+    with open(path) as fp:
+        for row in csv.DictReader(fp):
+            print("%-70s calls=%s total_ns=%s avg_ns=%s pct=%s" % (row.get("Name", "")[:70], row.get("Calls"),
+                  row.get("TotalDurationNs"), row.get("AverageNs"), row.get("Percentage")))
+print("== per-dispatch (kernel trace) of the alignment kernel ==")
+for path in find("trace/**/*kernel_trace.csv"):
+    with open(path) as fp:
+        for row in csv.DictReader(fp):
+            if "dtw_fused" in row.get("Kernel_Name", ""):
+                dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+                print("dur_ns=%d vgpr=%s sgpr=%s lds=%s scratch=%s grid=%s wg=%s %s" % (
+                    dur, row.get("VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"), row.get("Scratch_Size"),
+                    row.get("Grid_Size_X"), row.get("Workgroup_Size_X"), row["Kernel_Name"][:60]))
+print("== PMC (summed over dispatches of the alignment kernel; per-dispatch = /n_dispatch) ==")
+for d in find("pmc_*/"):
+    sums, n = defaultdict(float), defaultdict(int)
+    for path in glob.glob(os.path.join(d, "**/*counter_collection.csv"), recursive=True):
+        with open(path) as fp:
+            for row in csv.DictReader(fp):
+                if "dtw_fused" in row.get("Kernel_Name", ""):
+                    sums[row["Counter_Name"]] += float(row["Counter_Value"])
+                    n[row["Counter_Name"]] += 1
+    for k in sorted(sums):
+        print("%-28s per_dispatch=%.6g (n=%d)" % (k, sums[k] / max(n[k], 1), n[k]))
