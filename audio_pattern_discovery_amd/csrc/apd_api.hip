@@ -278,6 +278,42 @@ extern "C" uint64_t apd_slab_floats(uint32_t n_seq, uint32_t world)
     return ((t + world - 1) / world) * 2 * kSlotsPerTile;
 }
 
+extern "C" int apd_rank_tile_list(uint32_t n_seq, uint32_t rank, uint32_t world, uint32_t *tile_ab, uint64_t capacity,
+                                  uint64_t *n_tiles)
+{
+    if (world == 0 || rank >= world || !n_tiles) return APD_ERR_INVALID_ARG;
+    std::vector<uint2> tiles;
+    rank_tile_list(n_seq, rank, world, tiles);
+    *n_tiles = tiles.size();
+    if (tile_ab) {
+        if (capacity < tiles.size()) return APD_ERR_INVALID_ARG;
+        for (size_t t = 0; t < tiles.size(); ++t) { tile_ab[2 * t] = tiles[t].x; tile_ab[2 * t + 1] = tiles[t].y; }
+    }
+    return APD_OK;
+}
+
+extern "C" int apd_unpack_tiles_host(uint32_t n_seq, uint32_t world, const float *gathered, float *out)
+{
+    if (world == 0 || (n_seq && (!gathered || !out))) return APD_ERR_INVALID_ARG;
+    const uint64_t slab = apd_slab_floats(n_seq, world);
+    std::memset(out, 0, (size_t)n_seq * n_seq * sizeof(float));                 // alignments.rs:21-23
+    const uint32_t side = tiles_side(n_seq);
+    uint64_t g = 0;
+    for (uint32_t ta = 0; ta < side; ++ta)
+        for (uint32_t tb = ta; tb < side; ++tb, ++g) {
+            const float *t = gathered + (g % world) * slab + (g / world) * 2 * kSlotsPerTile;
+            for (uint32_t sa = 0; sa < kTile; ++sa)
+                for (uint32_t sb = 0; sb < kTile; ++sb) {
+                    const uint32_t a = ta * kTile + sa, b = tb * kTile + sb;
+                    if (a < b && b < n_seq) {
+                        out[(uint64_t)a * n_seq + b] = t[sa * kTile + sb];
+                        out[(uint64_t)b * n_seq + a] = t[kSlotsPerTile + sa * kTile + sb];
+                    }
+                }
+        }
+    return APD_OK;
+}
+
 static int check_lengths(const apd_batch *b)
 {
     if (b->n_seq > 0 && b->min_len == 0) return APD_ERR_EMPTY_SEQUENCE;

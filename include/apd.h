@@ -118,6 +118,11 @@ int apd_align_tiles_async(apd_context *ctx, const apd_batch *batch, const apd_al
                           uint32_t rank, uint32_t world, float *d_slab);
 int apd_unpack_tiles_async(apd_context *ctx, uint32_t n_seq, uint32_t world, const float *d_gathered,
                            float *d_out);
+/* Host-side views of the same sharding (no GPU needed): the (tile_a, tile_b) list of a rank, 2 uint32 per tile,
+ * and the scatter of gathered slabs held in HOST memory (for a host that gathers over its own transport). */
+int apd_rank_tile_list(uint32_t n_seq, uint32_t rank, uint32_t world, uint32_t *tile_ab, uint64_t capacity,
+                       uint64_t *n_tiles);
+int apd_unpack_tiles_host(uint32_t n_seq, uint32_t world, const float *gathered, float *out);
 
 /* Work accounting for the metric: cells = sum over ordered pairs of the
  * cells alignments.rs:174-175 visits; alg_bytes = sum of 4*dim*(n+m)+4. */

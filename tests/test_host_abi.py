@@ -1,0 +1,119 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol include/apd.h
+declares (no compute call is made: there is no GPU here), host-only entry points behave like the Rust
+items they replace, and the library refuses to run without a gfx950 device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from audio_pattern_discovery_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "apd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(apd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(apd):
+    L = apd.lib()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for name in names:
+        assert hasattr(L, name), "libapd_hip.so does not export %s" % name
+    bound = {n for n, _, _ in apd.SYMBOLS}
+    assert set(names) == bound, "ctypes table and apd.h disagree: %s" % (set(names) ^ bound)
+
+
+def test_no_cpu_fallback(apd):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(apd.ApdError) as e:
+        apd.Context(0)
+    assert e.value.status == apd.APD_ERR_NO_DEVICE
+
+
+def test_status_strings(apd):
+    L = apd.lib()
+    assert L.apd_status_string(0) == b"ok"
+    assert b"alignments.rs:120" in L.apd_status_string(apd.APD_ERR_EMPTY_SEQUENCE)
+    assert b"numerics.rs:132" in L.apd_status_string(apd.APD_ERR_INDEX)
+
+
+def test_discovery_alignment_params_matches_oracle(oracle):
+    from audio_pattern_discovery_amd.discovery import Discovery
+    d = Discovery(warping_band_percentage=0.0625, insertion_penalty=0.5, deletion_penalty=1.5, match_penalty=0.75)
+    for n in (0, 1, 15, 16, 17, 512, 1055, 2048, 1 << 20):
+        p = d.alignment_params(n)
+        assert p.warping_band == oracle.warping_band(0.0625, n)
+        assert (p.insertion_penalty, p.deletion_penalty, p.match_penalty) == (0.5, 1.5, 0.75)
+    assert Discovery(warping_band_percentage=-1.0).alignment_params(100).warping_band == 0
+    assert Discovery(warping_band_percentage=float("nan")).alignment_params(100).warping_band == 0
+    assert Discovery(warping_band_percentage=0.1).alignment_params(20).warping_band == oracle.warping_band(0.1, 20)
+
+
+def test_discovery_from_toml(tmp_path):
+    from audio_pattern_discovery_amd.discovery import Discovery
+    text = """# FFT Spec
+dft_win       = 256                  # DFT window
+dft_step      = 128
+ceps_filter   = 32
+auto_encoder  = 10
+learning_rate = 0.1
+epochs        = 25
+epoch_drop    = 5.0
+drop          = 0.5
+vat_moving     = 15
+vat_percentile = 0.95
+vat_min_len    = 150
+warping_band_percentage = 0.0625
+insertion_penalty       = 1.0
+deletion_penalty        = 1.0
+match_penalty           = 1.0
+alignment_workers       = 4
+clustering_percentile   = 0.05
+"""
+    f = tmp_path / "Discovery.toml"
+    f.write_text(text)
+    d = Discovery.from_toml(str(f))
+    assert d.dft_win == 256 and d.warping_band_percentage == 0.0625 and d.clustering_percentile == 0.05
+    (tmp_path / "bad.toml").write_text("dft_win = 1\n")
+    with pytest.raises(KeyError):
+        Discovery.from_toml(str(tmp_path / "bad.toml"))
+    with pytest.raises(OSError):
+        Discovery.from_toml(str(tmp_path / "missing.toml"))
+
+
+def test_align_work_counts_the_reference_loops(oracle):
+    from audio_pattern_discovery_amd import _lib
+    from audio_pattern_discovery_amd.alignments import align_work
+    frames, offsets = synth.make_sequences(37, 60, 13, seed=8, jitter=20)
+    for pct in (1.0, 0.0625, 0.0):
+        cfg = _lib.AlignConfig(pct, 1, 1, 1)
+        pairs, cells, nbytes = align_work(offsets, 13, cfg)
+        want_cells = want_bytes = 0
+        for i in range(37):
+            for j in range(37):
+                if i != j:
+                    n, m = int(offsets[i + 1] - offsets[i]), int(offsets[j + 1] - offsets[j])
+                    want_cells += oracle.dtw_cells(n, m, oracle.warping_band(pct, max(n, m)))
+                    want_bytes += 4 * 13 * (n + m) + 4
+        assert (pairs, cells, nbytes) == (37 * 36, want_cells, want_bytes)
+        # shards add up
+        parts = [align_work(offsets, 13, cfg, r, 3) for r in range(3)]
+        assert tuple(sum(p[k] for p in parts) for k in range(3)) == (pairs, cells, nbytes)
+
+
+def test_cluster_sets_host_matches_oracle(oracle):
+    from audio_pattern_discovery_amd.clustering import AgglomerativeClustering, ClusteringOperation, Merge
+    frames, offsets = synth.make_sequences(12, 16, 4, seed=5)
+    d = oracle.align_all(frames, offsets, 1.0, workers=4)
+    ops, roots, _ = oracle.clustering(d, 12, 0.4)
+    mine = [ClusteringOperation(o["merge_i"], o["merge_j"], o["into"], o["distance"], Merge[o["operation"]]) for o in ops]
+    assert AgglomerativeClustering.cluster_sets(mine, set(roots), 12) == oracle.cluster_sets(ops, roots, 12)
+    assert AgglomerativeClustering.cluster_sets([], {0, 1, 2}, 3) == []      # singletons omitted (clustering.rs:71)
