@@ -54,7 +54,7 @@ class AgglomerativeClustering:
         for t, o in enumerate(operations):
             ops[t] = _lib.ClusterOp(o.merge_i, o.merge_j, o.into, o.distance, int(o.operation))
         roots = np.array(sorted(cluster_ids), dtype=np.uint32)
-        members = np.zeros(max(n_instances, 1), dtype=np.uint32)
+        members = np.zeros(n_instances + len(operations) + 2, dtype=np.uint32)
         set_off = np.zeros(len(roots) + 2, dtype=np.uint32)
         n_sets = C.c_uint32(0)
         _lib.check(_lib.lib().apd_cluster_sets(ops, len(operations), roots.ctypes.data_as(C.POINTER(C.c_uint32)),

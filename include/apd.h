@@ -145,7 +145,7 @@ int apd_clustering(apd_context *ctx, const float *distances, int distances_on_de
                    float perc, apd_cluster_op *ops, uint32_t *n_ops, uint32_t *roots, uint32_t *n_roots,
                    float *threshold);
 /* AgglomerativeClustering::cluster_sets (src/clustering.rs:40-76); host-only bookkeeping.
- * members capacity >= n, set_off capacity >= n_roots+1. */
+ * members capacity >= n + n_ops + 2, set_off capacity >= n_roots+1. */
 int apd_cluster_sets(const apd_cluster_op *ops, uint32_t n_ops, const uint32_t *roots, uint32_t n_roots,
                      uint32_t n, uint32_t *members, uint32_t *set_off, uint32_t *n_sets);
 

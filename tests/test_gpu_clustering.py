@@ -1,0 +1,133 @@
+"""GPU parity tests of the percentile threshold and the UPGMA clustering (reference src/numerics.rs:125-133,
+src/clustering.rs:81-210) through the C ABI, against the literal CPU oracle.
+
+Tolerance: the merge SEQUENCE (merge_i, merge_j, into, Merge kind) must be identical; linkage distances within
+1e-5 relative (the device keeps running cluster sums, the reference re-adds raw distances: f32 association order
+differs).  Exact ties resolve to the lowest (id_i, id_j), as the oracle does."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from audio_pattern_discovery_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx(apd):
+    c = apd.Context(0)
+    yield c
+    c.close()
+
+
+def check_ops(got, want, n):
+    assert [(o.merge_i, o.merge_j, o.into, o.operation.name) for o in got] == \
+           [(o["merge_i"], o["merge_j"], o["into"], o["operation"]) for o in want]
+    for g, w in zip(got, want):
+        if np.isfinite(w["distance"]):
+            assert abs(g.distance - w["distance"]) <= 1e-5 * max(abs(w["distance"]), 1e-30)
+        else:
+            assert g.distance == w["distance"]
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "*.npz"))))
+def test_golden_clustering(ctx, oracle, path):
+    from audio_pattern_discovery_amd.clustering import AgglomerativeClustering
+    g = np.load(path)
+    if "dist" not in g:
+        pytest.skip("companion fixture")
+    n = len(g["offsets"]) - 1
+    perc = float(g["params"][4])
+    ops, roots, thr = AgglomerativeClustering.clustering(g["dist"], n, perc, ctx, return_threshold=True)
+    assert thr == float(g["threshold"])
+    assert [[o.merge_i, o.merge_j, o.into] for o in ops] == g["op_ij"].tolist()
+    assert [int(o.operation) for o in ops] == g["op_kind"].tolist()
+    assert sorted(roots) == g["roots"].tolist()
+    sets = AgglomerativeClustering.cluster_sets(ops, roots, n)
+    sizes = g["set_sizes"].tolist()
+    assert [len(s) for s in sets] == sizes and [m for s in sets for m in s] == g["set_members"].tolist()
+
+
+@pytest.mark.parametrize("n,perc,seed", [(9, 0.05, 1), (24, 0.3, 2), (40, 0.9, 3), (64, 0.05, 4), (33, 0.999, 5), (2, 0.5, 6), (1, 0.0, 7)])
+def test_random_matrices_match_literal_oracle(ctx, oracle, n, perc, seed):
+    from audio_pattern_discovery_amd.clustering import AgglomerativeClustering
+    frames, offsets = synth.make_sequences(n, 20, 4, seed=seed, jitter=6)
+    d = oracle.align_all(frames, offsets, 1.0, workers=8)
+    want_ops, want_roots, want_thr = oracle.clustering(d, n, perc)
+    ops, roots, thr = AgglomerativeClustering.clustering(d, n, perc, ctx, return_threshold=True)
+    assert thr == want_thr
+    check_ops(ops, want_ops, n)
+    assert sorted(roots) == want_roots
+    assert AgglomerativeClustering.cluster_sets(ops, roots, n) == oracle.cluster_sets(want_ops, want_roots, n)
+
+
+def test_directed_matrix_and_ties(ctx, oracle):
+    """Asymmetric distances (the band is asymmetric) and exact ties: lowest (id_i, id_j) wins, both orders count."""
+    from audio_pattern_discovery_amd.clustering import AgglomerativeClustering
+    rng = np.random.default_rng(0)
+    d = rng.integers(1, 6, size=(20, 20)).astype(np.float32)            # many exact ties, d[i][j] != d[j][i]
+    np.fill_diagonal(d, 0.0)
+    for perc in (0.2, 0.6, 0.95):
+        want_ops, want_roots, want_thr = oracle.clustering(d, 20, perc)
+        ops, roots, thr = AgglomerativeClustering.clustering(d, 20, perc, ctx, return_threshold=True)
+        assert thr == want_thr
+        check_ops(ops, want_ops, 20)
+        assert sorted(roots) == want_roots
+
+
+def test_infinite_distances_and_degenerate_merge(ctx, oracle):
+    """All linkages +INF: the reference merges its initial (0, 0) (clustering.rs:179) once and stops."""
+    from audio_pattern_discovery_amd.clustering import AgglomerativeClustering
+    d = np.full((5, 5), np.inf, dtype=np.float32)
+    np.fill_diagonal(d, 0.0)
+    want_ops, want_roots, want_thr = oracle.clustering(d, 5, 0.5)
+    ops, roots, thr = AgglomerativeClustering.clustering(d, 5, 0.5, ctx, return_threshold=True)
+    assert thr == want_thr == np.inf
+    check_ops(ops, want_ops, 5)
+    assert sorted(roots) == want_roots
+    # a finite block plus INF rows
+    d[:3, :3] = np.array([[0, 1, 4], [2, 0, 3], [5, 6, 0]], np.float32)
+    want_ops, want_roots, _ = oracle.clustering(d, 5, 0.9)
+    ops, roots = AgglomerativeClustering.clustering(d, 5, 0.9, ctx)
+    check_ops(ops, want_ops, 5)
+    assert sorted(roots) == want_roots
+
+
+def test_percentile_select_matches_sort(ctx, oracle, apd):
+    from audio_pattern_discovery_amd.clustering import percentile
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(100003).astype(np.float32) * 100
+    x[::97] = np.nan
+    x[5::1013] = np.inf
+    x[7::1013] = -np.inf
+    x[11::501] = 0.0
+    x[12::501] = -0.0
+    for perc in (0.0, 0.05, 0.5, 0.73, 0.98):
+        assert percentile(x, perc, ctx) == oracle.percentile(x, perc)
+    with pytest.raises(apd.ApdError) as e:
+        percentile(x, 0.999, ctx)                                   # index beyond the non-NaN count: the reference panics
+    assert e.value.status == apd.APD_ERR_INDEX
+    with pytest.raises(apd.ApdError):
+        percentile(np.arange(4, dtype=np.float32), 1.0, ctx)
+    # the index is computed in f32 from the UNFILTERED length (numerics.rs:126)
+    y = np.arange(4096 * 4096 // 64, dtype=np.float32)
+    assert percentile(y, 0.05, ctx) == oracle.percentile(y, 0.05)
+
+
+def test_end_to_end_align_then_cluster(ctx, oracle):
+    """main.rs:187-203: align_all -> clustering -> cluster_sets, GPU end to end, vs the oracle end to end."""
+    from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
+    from audio_pattern_discovery_amd.clustering import AgglomerativeClustering
+    from audio_pattern_discovery_amd.discovery import Discovery
+    frames, offsets = synth.make_sequences(48, 64, 13, seed=21, copies=0.5)
+    cfg = Discovery(warping_band_percentage=0.0625, clustering_percentile=0.05)
+    w = AlignmentWorkers.new([NDSequence(s) for s in synth.split(frames, offsets)], ctx)
+    w.align_all(cfg)
+    ops, roots = AgglomerativeClustering.clustering(w.result, 48, cfg.clustering_percentile, ctx)
+    d = oracle.align_all(frames, offsets, 0.0625, workers=8)
+    want_ops, want_roots, _ = oracle.clustering(d, 48, 0.05)
+    check_ops(ops, want_ops, 48)
+    assert sorted(roots) == want_roots
