@@ -22,6 +22,25 @@ class NDSequence:
         self.n_bins = int(a.shape[1])
         self.audio_id = audio_id
 
+    @staticmethod
+    def new(fft_size, fft_step, filter_size, raw_audio, ctx=None):
+        """NDSequence::new (spectrogram.rs:31-94), cepstrum branch: `raw_audio` is the i16 sample vector
+        (AudioData.data, audio.rs:10-14).  The plotting-only z-scored spectrogram is not produced."""
+        ctx = ctx or _lib.default_context()
+        s = np.ascontiguousarray(getattr(raw_audio, "data", raw_audio), dtype=np.int16)
+        nf, nb = C.c_uint64(0), C.c_uint32(0)
+        L = _lib.lib()
+        _lib.check(L.apd_cepstrum(ctx.handle, C.c_void_p(s.ctypes.data), s.size, fft_size, fft_step, filter_size, 0, None,
+                                  C.byref(nf), C.byref(nb)), ctx.handle)
+        out = np.empty((nf.value, nb.value), dtype=np.float32)
+        if nf.value:
+            _lib.check(L.apd_cepstrum(ctx.handle, C.c_void_p(s.ctypes.data), s.size, fft_size, fft_step, filter_size, 0,
+                                      C.c_void_p(out.ctypes.data), C.byref(nf), C.byref(nb)), ctx.handle)
+        return NDSequence(out, nb.value, getattr(raw_audio, "id", 0))
+
+    def encoded(self, nn, ctx=None):        # spectrogram.rs:103-121
+        return NDSequence(nn.predict_frames(self.frames, ctx), nn.n_latent(), self.audio_id)
+
     def vec(self, t):                       # spectrogram.rs:99-101
         return self.frames[t]
 

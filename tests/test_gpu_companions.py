@@ -1,0 +1,90 @@
+"""GPU parity tests of the feature companions against the CPU oracle.
+
+Encoder (neural.rs:55-71): same arithmetic order; expf differs from libm by <= 2 ulp -> 1e-5 relative.
+Cepstrum (spectrogram.rs:31-80): the reference's FFT/DCT come from un-vendored, un-pinned crates (rustfft 3.0.0,
+rustdct *), so this is PARITY UNPINNED against the reference; the oracle evaluates the mathematical definitions in
+f64, the kernel an f32 radix-2 FFT: agreement to 2e-4 absolute on values of magnitude ~1..10."""
+import os
+
+import numpy as np
+import pytest
+
+from audio_pattern_discovery_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "companions.npz")
+
+
+@pytest.fixture(scope="module")
+def ctx(apd):
+    c = apd.Context(0)
+    yield c
+    c.close()
+
+
+def test_encoder_golden_and_random(ctx, oracle):
+    from audio_pattern_discovery_amd.neural import AutoEncoder
+    g = np.load(GOLD)
+    nn = AutoEncoder(g["w"], g["b"])
+    assert nn.n_latent() == 8
+    np.testing.assert_allclose(nn.predict_frames(g["x"], ctx), g["enc"], rtol=1e-5, atol=1e-5)
+    rng = np.random.default_rng(3)
+    for d_in, latent, t in [(13, 8, 5000), (26, 10, 777), (13, 10, 1), (4, 3, 64)]:
+        x = (rng.standard_normal((t, d_in)) * 3).astype(np.float32)
+        w = ((rng.random((d_in, latent)) - 0.5) / latent).astype(np.float32)      # Mat::seeded scale (numerics.rs:182)
+        b = ((rng.random(latent) - 0.5) / latent).astype(np.float32)
+        got = AutoEncoder(w, b).predict_frames(x, ctx)
+        np.testing.assert_allclose(got, oracle.encode(x, w, b), rtol=1e-5, atol=1e-5)
+    # sigma is floored at 1.0 (neural.rs:62): constant latent -> zeros, not NaN
+    z = AutoEncoder(np.zeros((13, 8), np.float32), np.zeros(8, np.float32)).predict_frames(np.ones((3, 13), np.float32), ctx)
+    assert np.all(z == 0.0)
+
+
+def test_encoded_sequence_feeds_alignment(ctx, oracle):
+    """main.rs:150-161 then 187-195: cepstrum-like frames -> encoded(&nn) -> align_all, all on the GPU."""
+    from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
+    from audio_pattern_discovery_amd.discovery import Discovery
+    from audio_pattern_discovery_amd.neural import AutoEncoder
+    rng = np.random.default_rng(9)
+    w = ((rng.random((13, 8)) - 0.5) / 8).astype(np.float32)
+    b = ((rng.random(8) - 0.5) / 8).astype(np.float32)
+    frames, offsets = synth.make_sequences(12, 50, 13, seed=9)
+    nn = AutoEncoder(w, b)
+    seqs = [NDSequence(s).encoded(nn, ctx) for s in synth.split(frames, offsets)]
+    assert seqs[0].n_bins == 8
+    got = AlignmentWorkers.new(seqs, ctx).align_all(Discovery(warping_band_percentage=0.0625)).reshape(12, 12)
+    enc = oracle.encode(frames, w, b)
+    want = oracle.align_all(enc, offsets, 0.0625, workers=4)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6)
+
+
+def test_cepstrum_golden_and_shapes(ctx, oracle):
+    from audio_pattern_discovery_amd.alignments import NDSequence
+    g = np.load(GOLD)
+    s13 = NDSequence.new(256, 128, 18, g["audio"], ctx)            # ceps_filter 18 -> 13 bins
+    s26 = NDSequence.new(256, 128, 32, g["audio"], ctx)            # shipped config -> 26 bins
+    assert (s13.len(), s13.n_bins) == g["ceps13"].shape and (s26.len(), s26.n_bins) == g["ceps26"].shape
+    np.testing.assert_allclose(s13.frames, g["ceps13"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(s26.frames, g["ceps26"], rtol=0, atol=2e-4)
+    # frame count: i in (fft_size..n).step_by(step) (spectrogram.rs:51); n <= fft_size -> no frame
+    assert NDSequence.new(256, 128, 18, g["audio"][:256], ctx).len() == 0
+    assert NDSequence.new(256, 128, 18, g["audio"][:257], ctx).len() == 1
+    assert NDSequence.new(256, 128, 18, g["audio"][:385], ctx).len() == 2
+
+
+@pytest.mark.parametrize("fft,step,filt", [(256, 128, 18), (256, 64, 32), (512, 256, 32), (128, 32, 8), (1024, 512, 64)])
+def test_cepstrum_random_audio(ctx, oracle, fft, step, filt):
+    from audio_pattern_discovery_amd.alignments import NDSequence
+    audio = synth.make_audio(fft + step * 37 + 3, seed=fft + filt)
+    got = NDSequence.new(fft, step, filt, audio, ctx)
+    want = oracle.cepstrum(audio, fft, step, filt)
+    assert got.frames.shape == want.shape
+    np.testing.assert_allclose(got.frames, want, rtol=0, atol=3e-4)
+    assert np.abs(got.frames.mean(axis=1)).max() < 1e-4            # mean-centred bins (spectrogram.rs:74-75)
+
+
+def test_cepstrum_unsupported_window(ctx, apd):
+    from audio_pattern_discovery_amd.alignments import NDSequence
+    with pytest.raises(apd.ApdError) as e:
+        NDSequence.new(300, 128, 18, synth.make_audio(2000, seed=1), ctx)     # not a power of two
+    assert e.value.status == apd.APD_ERR_UNSUPPORTED
