@@ -184,6 +184,13 @@ def main():
             pj = (pi + 1 + rng.integers(0, n - 1, args.verify)).astype(np.uint32) % n
             want, _ = oracle.align_sample(frames, offsets, pi, pj, wl["pct"], workers=host_threads())
             verify = float(np.max(np.abs(result[pi, pj] - want) / np.maximum(np.abs(want), 1e-30)))
+        traffic = None
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(args.workload)
+            if rec and rec.get("n_gpus") == world:
+                traffic = rec["traffic_bytes"]        # measured by rocprofv3 PMC passes of this command (profiles/)
+        except (OSError, ValueError):
+            pass
         k_ms = float(np.mean(kernel_ms))
         achieved = bytes_r / (k_ms * 1e-3) / 1e9
         line = {
@@ -198,7 +205,7 @@ def main():
             "wall_clock_matrix_s": elapsed / args.steps,
             "pairs_per_s": pairs_all * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "dtw_fused (rank 0 share: %d ordered pairs)" % pairs_r,
                          "kernel_ms": k_ms, "alg_bytes_per_launch": bytes_r,
                          "kernel_cells_per_s": cells_r / (k_ms * 1e-3)},
