@@ -188,7 +188,7 @@ struct Geometry { int g, c; };
 // Pick the (lanes per pair, offsets per lane) that wastes the fewest lanes for a band of `need` offsets.
 static Geometry pick_geometry(uint32_t need)
 {
-    static const Geometry all[] = {{16, 2}, {16, 3}, {16, 5}, {16, 9}, {64, 3}, {64, 5}, {64, 9}};
+    static const Geometry all[] = {{16, 2}, {16, 3}, {16, 5}, {16, 9}, {64, 3}, {64, 5}, {64, 9}};   // (8, 9) only on request
     Geometry best{0, 0};
     double best_util = 0.0;
     for (const Geometry &q : all) {

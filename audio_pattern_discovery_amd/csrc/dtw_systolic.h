@@ -292,6 +292,7 @@ template <int D>
 bool launch_systolic(const AlignLaunch &L, int g, int c, bool uniform, hipStream_t stream)
 {
 #define APD_CASE(GG, CC) if (g == GG && c == CC) { launch_systolic_cg<D, CC, GG>(L, uniform, stream); return true; }
+    APD_CASE(8, 9)
     APD_CASE(16, 2) APD_CASE(16, 3) APD_CASE(16, 5) APD_CASE(16, 9)
     APD_CASE(64, 3) APD_CASE(64, 5) APD_CASE(64, 9)
 #undef APD_CASE
