@@ -18,7 +18,7 @@
 #include <type_traits>
 
 // Timing-only ablations for kernel tuning (results become wrong): build one unit with -DAPD_ABLATE=<bits>.
-//   1 no sqrt   2 no DP rows   4 no frame shifts   8 no edge fetches   16 no band guards
+//   1 no sqrt   2 no DP rows   4 no frame shifts   8 no edge fetches   16 no band guards   32 software-pipelined distances (valid results)
 #ifndef APD_ABLATE
 #define APD_ABLATE 0
 #endif
@@ -199,6 +199,12 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     read_row(xs[0], 0 - gl);                                     // macro-step 0: row -gl (all -INF)
 #pragma unroll
     for (int k = 0; k < D; ++k) xs[1][k] = 0.0f;
+    // Software pipeline: the first C-1 distances of macro-step tau+1 only need columns the lane already holds, so they
+    // are computed during macro-step tau, next to the serial DP chain; only the last column waits for the shift.
+    constexpr bool PIPE = (APD_ABLATE & 32) != 0;                  // measured: no gain on MI355X (cfg 3: -2 %), kept as a tuning switch
+    float dn[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) dn[c] = (PIPE && c < C - 1) ? frame_dist<D>(xs[0], yf[c]) : 0.0f;
 
     auto macro_steps = [&](int tau_begin, int tau_end, auto slow_tag) {
         constexpr bool SLOW = decltype(slow_tag)::value;
@@ -222,7 +228,11 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                 // the C local distances of this row
                 float d[C];
 #pragma unroll
-                for (int c = 0; c < C; ++c) d[c] = frame_dist<D>(xs[xa], yf[(r + c) % S]);
+                for (int c = 0; c < C; ++c) d[c] = (PIPE && c < C - 1) ? dn[c] : frame_dist<D>(xs[xa], yf[(r + c) % S]);
+                if (PIPE) {
+#pragma unroll
+                    for (int c = 0; c < C - 1; ++c) dn[c] = frame_dist<D>(xs[xb], yf[(r + 1 + c) % S]);
+                }
                 // the two DP rows
                 float left1 = group_from_lower<G>(prev1[C - 1], APD_INF, gl);
                 float left2 = group_from_lower<G>(prev2[C - 1], APD_INF, gl);

@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per leg (0 = skip)")
     ap.add_argument("--verify", type=int, default=64, help="entries re-checked against the oracle after timing")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo (staged through host memory) only to rehearse N>1 on a box with fewer GPUs")
     return ap.parse_args()
 
 
@@ -113,10 +115,14 @@ def main():
     from audio_pattern_discovery_amd import _lib, synth
     from audio_pattern_discovery_amd.alignments import align_work
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = int(os.environ.get("APD_FORCE_DEVICE", local_rank))      # rehearsal: several ranks on one GPU
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     wl = WORKLOADS[args.workload]
     n, dim = wl["n_seq"], wl["dim"]
@@ -126,7 +132,7 @@ def main():
     pairs_all, cells_all, bytes_all = align_work(offsets, dim, cfg, 0, 1)
     pairs_r, cells_r, bytes_r = align_work(offsets, dim, cfg, rank, world)
 
-    ctx = _lib.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    ctx = _lib.Context(dev_index, stream=torch.cuda.current_stream().cuda_stream)
     ctx.selftest()
     ctx.set_variant(args.variant)
     ctx.set_timing(True)
@@ -144,8 +150,12 @@ def main():
                                       n, dim, 1, C.byref(batch)), ctx.handle)
         _lib.check(L.apd_align_tiles_async(ctx.handle, batch, C.byref(cfg), rank, world, C.c_void_p(d_slab.data_ptr())),
                    ctx.handle)
-        if world > 1:
+        if world > 1 and args.backend == "nccl":
             dist.all_gather_into_tensor(d_gathered, d_slab)          # the one collective (RCCL over xGMI)
+        elif world > 1:
+            host = torch.empty(slab_floats * world, dtype=torch.float32)
+            dist.all_gather_into_tensor(host, d_slab.cpu())          # rehearsal path only
+            d_gathered.copy_(host)
         _lib.check(L.apd_unpack_tiles_async(ctx.handle, n, world, C.c_void_p(d_gathered.data_ptr()),
                                             C.c_void_p(d_out.data_ptr())), ctx.handle)
         return batch
