@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per leg (0 = skip)")
     ap.add_argument("--verify", type=int, default=64, help="entries re-checked against the oracle after timing")
+    ap.add_argument("--cluster", action="store_true", help="also time percentile + UPGMA (rank 0, outside the timed region)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (staged through host memory) only to rehearse N>1 on a box with fewer GPUs")
     return ap.parse_args()
@@ -221,6 +222,17 @@ def main():
                          "kernel_cells_per_s": cells_r / (k_ms * 1e-3)},
             "max_rel_err_vs_oracle": verify,
         }
+        if args.cluster:
+            ops = (_lib.ClusterOp * n)()
+            roots = np.zeros(n, dtype=np.uint32)
+            n_ops, n_roots, thr = C.c_uint32(0), C.c_uint32(0), C.c_float(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _lib.check(L.apd_clustering(ctx.handle, C.c_void_p(d_out.data_ptr()), 1, n, 0.05, ops, C.byref(n_ops),
+                                        roots.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n_roots), C.byref(thr)), ctx.handle)
+            line["clustering"] = {"seconds": time.perf_counter() - t0, "merges": int(n_ops.value), "roots": int(n_roots.value),
+                                  "threshold": float(thr.value), "percentile": 0.05,
+                                  "note": "apd_clustering on the resident matrix: radix-select threshold + UPGMA (clustering.rs:81-110)"}
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(frames, offsets, wl, args.cpu_seconds)
         else:

@@ -188,3 +188,44 @@ def test_full_size_properties_cfg2(ctx, oracle):
     o2 = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint64)
     g2 = gpu_align_all(ctx, f2, o2, 13, 0.0625)
     assert g2[3, 8] == 0.0 and g2[8, 3] == 0.0
+
+
+def test_full_size_properties_cfg3(ctx, oracle):
+    """BASELINE cfg 3 shape (4096 x len~1024, band 64: 16.8 M ordered pairs) through the device entry points:
+    size-independent properties + sampled entries against the oracle + a checksum that must not depend on how
+    the pair tiles are sharded (world 1 vs world 4 slabs)."""
+    import torch
+    from audio_pattern_discovery_amd.alignments import Batch
+    from audio_pattern_discovery_amd.discovery import Discovery
+    from audio_pattern_discovery_amd import _lib
+    n = 4096
+    frames, offsets = synth.make_sequences(n, 1024, 13, seed=0xA9D3)
+    frames[int(offsets[77]):int(offsets[78])] = 0.0                        # a constant sequence ...
+    frames[int(offsets[78]):int(offsets[78]) + 5] = 0.0                     # ... and a neighbour sharing 5 leading frames
+    cfg = Discovery(warping_band_percentage=0.0625).align_config()
+    L = _lib.lib()
+    batch = Batch(ctx, frames, offsets, 13)
+    out = torch.empty(n * n, dtype=torch.float32, device="cuda")
+    _lib.check(L.apd_align_all_device_async(ctx.handle, batch.handle, C.byref(cfg), C.c_void_p(out.data_ptr())), ctx.handle)
+    ctx.synchronize()
+    got = out.cpu().numpy().reshape(n, n)
+    assert np.all(np.diag(got) == 0.0)
+    off = ~np.eye(n, dtype=bool)
+    assert np.all(np.isfinite(got[off])) and np.all(got[off] >= 0)
+    rng = np.random.default_rng(1)
+    pi = np.concatenate([rng.integers(0, n, 300), [77, 78, 0, n - 1]]).astype(np.uint32)
+    pj = np.concatenate([rng.integers(0, n, 300), [78, 77, n - 1, 0]]).astype(np.uint32)
+    keep = pi != pj
+    want, _ = oracle.align_sample(frames, offsets, pi[keep], pj[keep], 0.0625, workers=8)
+    assert_parity(got[pi[keep], pj[keep]], want)
+    # sharding invariance: 4 slabs computed separately, unpacked, give the identical matrix (bitwise)
+    world = 4
+    slab = int(L.apd_slab_floats(n, world))
+    gathered = torch.zeros(world * slab, dtype=torch.float32, device="cuda")
+    for r in range(world):
+        _lib.check(L.apd_align_tiles_async(ctx.handle, batch.handle, C.byref(cfg), r, world,
+                                           C.c_void_p(gathered.data_ptr() + 4 * r * slab)), ctx.handle)
+    out2 = torch.empty(n * n, dtype=torch.float32, device="cuda")
+    _lib.check(L.apd_unpack_tiles_async(ctx.handle, n, world, C.c_void_p(gathered.data_ptr()), C.c_void_p(out2.data_ptr())), ctx.handle)
+    ctx.synchronize()
+    assert torch.equal(out, out2)
