@@ -62,6 +62,7 @@ SYMBOLS = [
     ("apd_set_timing", C.c_int, [_vp, C.c_int]),
     ("apd_last_kernel_ms", C.c_float, [_vp]),
     ("apd_set_variant", C.c_int, [_vp, C.c_int]),
+    ("apd_set_distance_mode", C.c_int, [_vp, C.c_int, C.c_float]),
     ("apd_selftest", C.c_int, [_vp]),
     ("apd_discovery_alignment_params", C.c_int, [C.POINTER(AlignConfig), C.c_uint64, C.POINTER(AlignmentParamsC)]),
     ("apd_batch_create", C.c_int, [_vp, _vp, _u64p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_vp)]),
@@ -149,6 +150,11 @@ class Context:
 
     def set_variant(self, v):
         check(lib().apd_set_variant(self.handle, int(v)))
+
+    def set_distance_mode(self, mode, tau=0.0):
+        """0 / "exact": difference form; 1 / "hybrid": norm expansion with exact recomputation below tau."""
+        mode = {"exact": 0, "hybrid": 1}.get(mode, mode)
+        check(lib().apd_set_distance_mode(self.handle, int(mode), float(tau)))
 
     def selftest(self):
         check(lib().apd_selftest(self.handle), self.handle)

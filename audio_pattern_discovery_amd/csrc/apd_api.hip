@@ -156,6 +156,14 @@ extern "C" int apd_set_variant(apd_context *ctx, int variant)
     return APD_OK;
 }
 
+extern "C" int apd_set_distance_mode(apd_context *ctx, int mode, float tau)
+{
+    if (!ctx || (mode != 0 && mode != 1) || !(tau >= 0.0f)) return APD_ERR_INVALID_ARG;
+    ctx->distance_mode = mode;
+    if (tau > 0.0f) ctx->tau = tau;
+    return APD_OK;
+}
+
 extern "C" int apd_selftest(apd_context *ctx)
 {
     if (!ctx) return APD_ERR_INVALID_ARG;
@@ -198,14 +206,14 @@ extern "C" int apd_batch_create(apd_context *ctx, const float *frames, const uin
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint64_t total = offsets[n_seq];
     if (total > 0 && !frames) return APD_ERR_INVALID_ARG;
-    if (total + n_seq >= (1ull << 32) || offsets[0] != 0) return APD_ERR_INVALID_ARG;
+    if (total + 2ull * n_seq >= (1ull << 32) || offsets[0] != 0) return APD_ERR_INVALID_ARG;
     apd_batch *b = new (std::nothrow) apd_batch();
     if (!b) return APD_ERR_OOM;
-    b->ctx = ctx; b->n_seq = n_seq; b->dim = dim; b->dpad = (dim + 3) & ~3u; b->total_frames = total;
+    b->ctx = ctx; b->n_seq = n_seq; b->dim = dim; b->dpad = (dim + 4) & ~3u;   /* dim components + squared norm, padded to 16 bytes */ b->total_frames = total;
     b->offsets.assign(offsets, offsets + n_seq + 1);
     b->min_len = 0xFFFFFFFFu; b->max_len = 0;
     std::vector<uint32_t> off32(n_seq + 1);
-    for (uint32_t s = 0; s <= n_seq; ++s) off32[s] = (uint32_t)offsets[s] + s;   // one sentinel frame behind every sequence
+    for (uint32_t s = 0; s <= n_seq; ++s) off32[s] = (uint32_t)offsets[s] + 2 * s;   // two sentinel frames behind every sequence
     for (uint32_t s = 0; s < n_seq; ++s) {
         if (offsets[s + 1] < offsets[s]) { delete b; return APD_ERR_INVALID_ARG; }
         const uint32_t len = (uint32_t)(offsets[s + 1] - offsets[s]);
@@ -214,7 +222,7 @@ extern "C" int apd_batch_create(apd_context *ctx, const float *frames, const uin
     }
     if (n_seq == 0) b->min_len = 0;
     auto fail = [&](int rc) { apd_batch_destroy(b); return rc; };
-    const uint64_t padded_frames = total + n_seq;
+    const uint64_t padded_frames = total + 2ull * n_seq;
     const size_t padded_bytes = std::max<size_t>((size_t)padded_frames * b->dpad * sizeof(float), 16);
     b->frames_bytes = padded_bytes < 0xFFFFFE00ull ? (uint32_t)padded_bytes : 0u;
     if (hipMalloc((void **)&b->d_frames, padded_bytes) != hipSuccess) return fail(APD_ERR_OOM);
@@ -342,6 +350,7 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
     L.d_frames = batch->d_frames; L.frames_bytes = batch->frames_bytes; L.d_seq_off = batch->d_seq_off; L.d_tiles = entry.first; L.n_tiles = entry.second;
     L.n_seq = batch->n_seq; L.dim = batch->dim; L.dpad = batch->dpad; L.band = band; L.d_slab = d_slab;
     L.variant = ctx->variant;
+    L.hybrid = ctx->distance_mode; L.tau = ctx->tau;
     // upper bound of w over all pairs: the band is monotone in max(n,m), the gap is at most max_len - min_len
     {
         const uint32_t band_ub = band.use_explicit ? band.explicit_band : host_band_from_pct(band.pct, batch->max_len);

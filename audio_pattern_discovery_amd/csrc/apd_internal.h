@@ -26,9 +26,9 @@ struct BandSpec {
 
 // One launch of the fused-pair alignment over a list of tiles.
 struct AlignLaunch {
-    const float *d_frames;       // [total_frames + n_seq][dpad]: zero padded dims, one +INF sentinel frame behind every sequence
+    const float *d_frames;       // resident layout, see dtw_generic.hip: [frames | sentinel H | sentinel E] per sequence, dpad floats per frame
     uint32_t frames_bytes;       // size of d_frames in bytes (0 if >= 4 GiB: buffer addressing unavailable)
-    const uint32_t *d_seq_off;   // [n_seq+1] padded frame offsets (sequence s owns seq_off[s+1]-seq_off[s]-1 real frames)
+    const uint32_t *d_seq_off;   // [n_seq+1] padded frame offsets (sequence s owns seq_off[s+1]-seq_off[s]-2 real frames)
     const uint2 *d_tiles;        // [n_tiles] (tile_a, tile_b), tile_a <= tile_b
     uint32_t n_tiles;
     uint32_t n_seq;
@@ -37,6 +37,8 @@ struct AlignLaunch {
     float *d_slab;               // [n_tiles][2][kTile][kTile]
     uint32_t w_max;              // upper bound of w over the pairs of this launch
     int variant;                 // 0 auto
+    int hybrid;                  // 1: norm-expansion distances with exact recomputation below tau (see dtw_systolic.h)
+    float tau;
 };
 
 hipError_t launch_align(const AlignLaunch &L, hipStream_t stream, std::string &err, int *status);
@@ -72,6 +74,8 @@ struct apd_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int variant = 0;
+    int distance_mode = 1;            // 0 exact differences, 1 hybrid
+    float tau = 1.0f / 64.0f;
     std::string last_error;
     // reusable device workspaces
     void *ws_tiles = nullptr; size_t ws_tiles_bytes = 0;

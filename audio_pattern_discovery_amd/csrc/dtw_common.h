@@ -79,7 +79,8 @@ __device__ __forceinline__ float select_node(float del_v, float ins_v, float m_v
 }
 
 // One unordered pair (a < b) of a tile.  Frames of sequence s live at d_frames[(seq_off[s] + t) * dpad], t in
-// [0, len), followed by ONE sentinel frame of +INF (index len) used for columns j <= 0.
+// [0, len), followed by two sentinel frames used for columns j <= 0 (index len: zero components, norm +INF;
+// index len + 1: +INF components).
 struct PairInfo {
     const float *A, *B;
     int n, m, w;
@@ -100,8 +101,8 @@ __device__ __forceinline__ PairInfo decode_pair(const AlignLaunch &L, uint32_t t
     if (!((a < b) && (b < L.n_seq))) return p;
     p.valid = true;
     const uint32_t oa = L.d_seq_off[a], ob = L.d_seq_off[b];
-    p.n = (int)(L.d_seq_off[a + 1] - oa) - 1;
-    p.m = (int)(L.d_seq_off[b + 1] - ob) - 1;
+    p.n = (int)(L.d_seq_off[a + 1] - oa) - 2;
+    p.m = (int)(L.d_seq_off[b + 1] - ob) - 2;
     p.A = L.d_frames + (uint64_t)oa * L.dpad;
     p.B = L.d_frames + (uint64_t)ob * L.dpad;
     p.w = pair_w(L.band, p.n, p.m);
@@ -118,7 +119,7 @@ __device__ __forceinline__ void store_pair(const AlignLaunch &L, uint32_t tile, 
 // Host launchers of the templated systolic kernel, one translation unit per frame dimension.
 // Returns false when (G, C) is not instantiated.
 template <int D>
-bool launch_systolic(const AlignLaunch &L, int g, int c, bool uniform_pen, hipStream_t stream);
+bool launch_systolic(const AlignLaunch &L, int g, int c, bool uniform_pen, hipStream_t stream);   // L.hybrid selects the distance form
 extern template bool launch_systolic<8>(const AlignLaunch &, int, int, bool, hipStream_t);
 extern template bool launch_systolic<10>(const AlignLaunch &, int, int, bool, hipStream_t);
 extern template bool launch_systolic<13>(const AlignLaunch &, int, int, bool, hipStream_t);

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64) void dtw_fused_generic(const AlignLaunch L, int
     C = max(C, 2);
     float *p1 = lds, *p2 = lds + c_max * 64;               // [c][lane]
     for (int c = 0; c < C; ++c) { p1[c * 64 + lane] = APD_INF; p2[c * 64 + lane] = APD_INF; }
-    const int dp4 = (int)L.dpad / 4;
+    const int dp4 = (int)L.dpad / 4, dim = (int)L.dim;
     const int u0 = C * lane;
     const int g_act = (two_w + 1 + C - 1) / C;
     const int total = (n - 1) + g_act;
@@ -65,13 +65,14 @@ __global__ __launch_bounds__(64) void dtw_fused_generic(const AlignLaunch L, int
             const int j = jb + c, u = u0 + c;
             const float4 *yb = reinterpret_cast<const float4 *>(P.B + (uint64_t)(min(max(j, 1), m) - 1) * L.dpad);
             float acc = 0.0f;
-            for (int q = 0; q < dp4; ++q) {                  // zero padded dims add exactly 0
+            for (int q = 0; q < dp4; ++q) {                  // slots >= dim hold the squared norm / padding: skipped
                 const float4 xv = xa[q], yv = yb[q];
+                const int k0 = 4 * q;
                 float t = xv.x - yv.x;
-                acc = (q == 0) ? t * t : __builtin_fmaf(t, t, acc);
-                t = xv.y - yv.y; acc = __builtin_fmaf(t, t, acc);
-                t = xv.z - yv.z; acc = __builtin_fmaf(t, t, acc);
-                t = xv.w - yv.w; acc = __builtin_fmaf(t, t, acc);
+                acc = (q == 0) ? t * t : ((k0 < dim) ? __builtin_fmaf(t, t, acc) : acc);
+                t = xv.y - yv.y; acc = (k0 + 1 < dim) ? __builtin_fmaf(t, t, acc) : acc;
+                t = xv.z - yv.z; acc = (k0 + 2 < dim) ? __builtin_fmaf(t, t, acc) : acc;
+                t = xv.w - yv.w; acc = (k0 + 3 < dim) ? __builtin_fmaf(t, t, acc) : acc;
             }
             const float d = __builtin_amdgcn_sqrtf(acc);
             const float m1 = nxt1, m2 = nxt2;
@@ -100,8 +101,9 @@ __global__ __launch_bounds__(64) void dtw_fused_generic(const AlignLaunch L, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// Resident layout: [frames of seq 0 | +INF sentinel | frames of seq 1 | +INF sentinel | ...], every frame
-// padded to dpad floats (zeros).  seq_off[s] = offsets[s] + s.
+// Resident layout: per sequence [frames | sentinel H | sentinel E], seq_off[s] = offsets[s] + 2 s.  A frame is dpad =
+// ceil4(dim + 1) floats: the dim components, then the squared norm sum_k x_k^2 (slot dim), then zeros.  Sentinel H has
+// zero components and norm +INF (hybrid distances), sentinel E has +INF components (difference-form distances).
 // ------------------------------------------------------------------------------------------------
 __global__ void pad_frames_kernel(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ seq_off,
                                   uint32_t n_seq, uint64_t n_frames_padded, uint32_t dim, uint32_t dpad)
@@ -112,9 +114,15 @@ __global__ void pad_frames_kernel(const float *__restrict__ src, float *__restri
         const uint32_t k = (uint32_t)(e - (uint64_t)f * dpad);
         uint32_t lo = 0, hi = n_seq;                          // largest s with seq_off[s] <= f
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seq_off[mid] <= f) lo = mid; else hi = mid; }
-        const bool sentinel = (f + 1 == seq_off[lo + 1]);
+        const bool sent_e = (f + 1 == seq_off[lo + 1]), sent_h = (f + 2 == seq_off[lo + 1]);
         float v = 0.0f;
-        if (k < dim) v = sentinel ? APD_INF : src[(uint64_t)(f - lo) * dim + k];
+        if (sent_e) v = (k <= dim) ? APD_INF : 0.0f;
+        else if (sent_h) v = (k == dim) ? APD_INF : 0.0f;
+        else {
+            const float *fr = src + (uint64_t)(f - 2 * lo) * dim;
+            if (k < dim) v = fr[k];
+            else if (k == dim) { double acc = 0.0; for (uint32_t t = 0; t < dim; ++t) acc += (double)fr[t] * (double)fr[t]; v = (float)acc; }
+        }
         dst[e] = v;
     }
 }
@@ -186,13 +194,13 @@ hipError_t launch_unpack(const float *d_gathered, float *d_out, uint32_t n_seq, 
 struct Geometry { int g, c; };
 
 // Pick the (lanes per pair, offsets per lane) that wastes the fewest lanes for a band of `need` offsets.
-static Geometry pick_geometry(uint32_t need)
+static Geometry pick_geometry(uint32_t need, uint32_t dim)
 {
     static const Geometry all[] = {{16, 2}, {16, 3}, {16, 5}, {16, 9}, {64, 3}, {64, 5}, {64, 9}};   // (8, 9) only on request
     Geometry best{0, 0};
     double best_util = 0.0;
     for (const Geometry &q : all) {
-        if ((uint32_t)(q.g * q.c) < need) continue;
+        if ((uint32_t)(q.g * q.c) < need || (q.c == 9 && dim > 16)) continue;
         const double util = (double)need / (double)(q.g * q.c) - 0.004 * (9 - q.c);   // larger C: fewer exchanges per cell
         if (util > best_util) { best_util = util; best = q; }
     }
@@ -209,15 +217,17 @@ hipError_t launch_align(const AlignLaunch &L, hipStream_t stream, std::string &e
     const bool pens_ok = (b.ins > 0.0f) && (b.del > 0.0f) && (b.mat > 0.0f) && (b.ins < APD_INF) && (b.del < APD_INF) &&
                          (b.mat < APD_INF);
     bool done = false;
+    AlignLaunch LL = L;
+    if (LL.dim < 10) LL.hybrid = 0;            // the norm expansion saves D - 4 vector ops per cell: not worth its branch below D = 10
     if (L.variant != 1 && pens_ok && L.frames_bytes != 0) {
-        Geometry q = pick_geometry(2 * L.w_max + 1);
+        Geometry q = pick_geometry(2 * L.w_max + 1, L.dim);
         if (L.variant >= 100) { q.g = L.variant / 100; q.c = L.variant % 100; if ((uint32_t)(q.g * q.c) < 2 * L.w_max + 1) q.g = 0; }
         if (q.g != 0) {
             switch (L.dim) {
-                case 8: done = launch_systolic<8>(L, q.g, q.c, uniform, stream); break;
-                case 10: done = launch_systolic<10>(L, q.g, q.c, uniform, stream); break;
-                case 13: done = launch_systolic<13>(L, q.g, q.c, uniform, stream); break;
-                case 26: done = launch_systolic<26>(L, q.g, q.c, uniform, stream); break;
+                case 8: done = launch_systolic<8>(LL, q.g, q.c, uniform, stream); break;   // L.hybrid picks the distance form
+                case 10: done = launch_systolic<10>(LL, q.g, q.c, uniform, stream); break;
+                case 13: done = launch_systolic<13>(LL, q.g, q.c, uniform, stream); break;
+                case 26: done = launch_systolic<26>(LL, q.g, q.c, uniform, stream); break;
                 default: break;
             }
         }

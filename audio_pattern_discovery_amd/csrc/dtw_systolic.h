@@ -57,8 +57,8 @@ __device__ __forceinline__ void load_frame_dwords(float (&dst)[D], __amdgpu_buff
 }
 
 // numerics.rs:114-120 as an fma chain, k ascending; v_sqrt_f32 (<= 1 ulp).
-template <int D>
-__device__ __forceinline__ float frame_dist(const float (&x)[D], const float (&y)[D])
+template <int D, int DN>
+__device__ __forceinline__ float frame_dist(const float (&x)[DN], const float (&y)[DN])
 {
     float t = x[0] - y[0];
     float acc = t * t;
@@ -71,11 +71,35 @@ __device__ __forceinline__ float frame_dist(const float (&x)[D], const float (&y
     return __builtin_amdgcn_sqrtf(acc);
 }
 
-template <int D, int C, int G, bool UNIFORM_PEN>
+// Squared distance by norm expansion: x[D], y[D] hold the squared norms.  13 fma + 2 instead of 26 (D = 13).
+template <int D>
+__device__ __forceinline__ float frame_sq_expanded(const float (&x)[D + 1], const float (&y)[D + 1], float &s_out)
+{
+    float dot = x[0] * y[0];
+#pragma unroll
+    for (int k = 1; k < D; ++k) dot = __builtin_fmaf(x[k], y[k], dot);
+    s_out = x[D] + y[D];
+    return __builtin_fmaf(-2.0f, dot, s_out);
+}
+template <int D>
+__device__ __forceinline__ float frame_sq_exact(const float (&x)[D + 1], const float (&y)[D + 1])
+{
+    float t = x[0] - y[0];
+    float acc = t * t;
+#pragma unroll
+    for (int k = 1; k < D; ++k) {
+        t = x[k] - y[k];
+        acc = __builtin_fmaf(t, t, acc);
+    }
+    return acc;
+}
+
+template <int D, int C, int G, bool UNIFORM_PEN, bool HYBRID>
 __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
 {
     static_assert(C >= 2 && (64 % G) == 0, "bad geometry");
-    constexpr int DP = (D + 3) & ~3;
+    constexpr int DN = D + 1;                                  // frame components + squared norm
+    constexpr int DP = (DN + 3) & ~3;                          // floats per resident frame
     constexpr int PPW = 64 / G;                                // pairs per wave
     constexpr int WPT = kSlotsPerTile / (4 * PPW);             // workgroups per tile
     const int lane = threadIdx.x & 63;
@@ -149,19 +173,19 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     float res1 = 0.0f, res2 = 0.0f;
 
     // window at macro-step 0: column j = -gl + u0 + c - w in slot c; columns <= 0 read the +INF sentinel (index m)
-    float yf[S][D];
+    float yf[S][DN];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const int j = u0 - gl + c - w;
-        const int idx = (j >= 1) ? (min(j, m) - 1) : m;
-        load_frame<D>(yf[c], rsrc, b_off + (uint32_t)idx * FB);
+        const int idx = (j >= 1) ? (min(j, m) - 1) : (HYBRID ? m : m + 1);   // sentinel H / sentinel E
+        load_frame<DN>(yf[c], rsrc, b_off + (uint32_t)idx * FB);
     }
 #pragma unroll
-    for (int k = 0; k < D; ++k) yf[C][k] = 0.0f;
+    for (int k = 0; k < DN; ++k) yf[C][k] = 0.0f;
     // ring prologue: rows -(G-1)..0 are -INF, rows 1..U come from memory
     constexpr int NFILL = (U + FPF - 1) / FPF;
     const int fill_f = lane / LPF, fill_q = lane % LPF;          // this lane's frame and 16-byte piece inside a fill
-    auto fill_load = [&](int first_row, apd_f32x4 (&regs)[NFILL]) {
+    auto fill_load = [&](int first_row, apd_f32x4 (&regs)[NFILL]) __attribute__((always_inline)) {
 #pragma unroll
         for (int f = 0; f < NFILL; ++f) {
             const int fi = f * FPF + fill_f;
@@ -170,7 +194,7 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
             regs[f] = __builtin_bit_cast(apd_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, act ? off : kNoFrame, 0, 0));
         }
     };
-    auto fill_store = [&](int first_row, const apd_f32x4 (&regs)[NFILL]) {
+    auto fill_store = [&](int first_row, const apd_f32x4 (&regs)[NFILL]) __attribute__((always_inline)) {
 #pragma unroll
         for (int f = 0; f < NFILL; ++f) {
             const int fi = f * FPF + fill_f;
@@ -178,35 +202,37 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                 *reinterpret_cast<apd_f32x4 *>(&xring[((first_row + fi) & (R - 1)) * DP + 4 * fill_q]) = regs[f];
         }
     };
-    for (int e = lane; e < G * DP; e += 64) xring[((-(e / DP)) & (R - 1)) * DP + (e % DP)] = -APD_INF;
+    for (int e = lane; e < G * DP; e += 64)                      // rows <= 0: -INF components, or (hybrid) zeros with norm +INF
+        xring[((-(e / DP)) & (R - 1)) * DP + (e % DP)] = HYBRID ? ((e % DP) == D ? APD_INF : 0.0f) : -APD_INF;
     {
         apd_f32x4 regs[NFILL];
         fill_load(1, regs);
         fill_store(1, regs);
     }
-    auto read_row = [&](float (&dst)[D], int row) {
+    auto read_row = [&](float (&dst)[DN], int row) __attribute__((always_inline)) {
         const float *p = &xring[(row & (R - 1)) * DP];
 #pragma unroll
         for (int q = 0; q < LPF; ++q) {
             const apd_f32x4 t = *reinterpret_cast<const apd_f32x4 *>(p + 4 * q);
-            if (4 * q + 0 < D) dst[4 * q + 0] = t.x;
-            if (4 * q + 1 < D) dst[4 * q + 1] = t.y;
-            if (4 * q + 2 < D) dst[4 * q + 2] = t.z;
-            if (4 * q + 3 < D) dst[4 * q + 3] = t.w;
+            if (4 * q + 0 < DN) dst[4 * q + 0] = t.x;
+            if (4 * q + 1 < DN) dst[4 * q + 1] = t.y;
+            if (4 * q + 2 < DN) dst[4 * q + 2] = t.z;
+            if (4 * q + 3 < DN) dst[4 * q + 3] = t.w;
         }
     };
-    float xs[2][D];
+    constexpr int NX = HYBRID ? 1 : 2;                           // hybrid: one row-frame set (registers are the limit)
+    float xs[NX][DN];
     read_row(xs[0], 0 - gl);                                     // macro-step 0: row -gl (all -INF)
 #pragma unroll
-    for (int k = 0; k < D; ++k) xs[1][k] = 0.0f;
+    for (int k = 0; k < DN; ++k) xs[NX - 1][k] = (NX == 1) ? xs[0][k] : 0.0f;
     // Software pipeline: the first C-1 distances of macro-step tau+1 only need columns the lane already holds, so they
     // are computed during macro-step tau, next to the serial DP chain; only the last column waits for the shift.
     constexpr bool PIPE = (APD_ABLATE & 32) != 0;                  // measured: no gain on MI355X (cfg 3: -2 %), kept as a tuning switch
     float dn[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) dn[c] = (PIPE && c < C - 1) ? frame_dist<D>(xs[0], yf[c]) : 0.0f;
+    for (int c = 0; c < C; ++c) dn[c] = (PIPE && !HYBRID && c < C - 1) ? frame_dist<D, DN>(xs[0], yf[c]) : 0.0f;
 
-    auto macro_steps = [&](int tau_begin, int tau_end, auto slow_tag) {
+    auto macro_steps = [&](int tau_begin, int tau_end, auto slow_tag) __attribute__((always_inline)) {
         constexpr bool SLOW = decltype(slow_tag)::value;
         for (int tau0 = tau_begin; tau0 < tau_end; tau0 += U) {
             apd_f32x4 fill_regs[NFILL];
@@ -215,23 +241,46 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
             for (int q = 0; q < U; ++q) {
                 const int tau = tau0 + q;
                 const int r = q % S;               // slot of this step's first column
-                const int xa = q & 1, xb = xa ^ 1; // current / next row-frame set
+                const int xa = HYBRID ? 0 : (q & 1), xb = HYBRID ? 0 : (xa ^ 1);   // current / next row-frame set
                 const int e = (r + C) % S;         // slot of the column entering at tau + 1 (dead during this step)
                 // column frame entering the group at tau + 1: fetched by the top lane straight into the dead slot
                 // (other lanes' offsets are out of range: no memory access, and the DPP below overwrites them)
                 {
                     const int jt = tau + 1 + (C - 1) * G - w;
-                    const uint32_t yo = b_off + (uint32_t)((jt >= 1) ? (min(jt, m) - 1) : m) * FB;
-                    if (!(APD_ABLATE & 8)) load_frame<D>(yf[e], rsrc, gl == G - 1 ? yo : kNoFrame);
-                    read_row(xs[xb], tau + 1 - gl);               // next row frame from the wave's LDS ring
+                    const uint32_t yo = b_off + (uint32_t)((jt >= 1) ? (min(jt, m) - 1) : (HYBRID ? m : m + 1)) * FB;
+                    if (!(APD_ABLATE & 8)) load_frame<DN>(yf[e], rsrc, gl == G - 1 ? yo : kNoFrame);
+                    if (!HYBRID) read_row(xs[xb], tau + 1 - gl);  // next row frame from the wave's LDS ring
                 }
                 // the C local distances of this row
                 float d[C];
+                if (HYBRID) {
+                    // |x|^2 + |y|^2 - 2 x.y; where that is below tau (|x|^2 + |y|^2) cancellation has eaten the digits:
+                    // such cells are recomputed in the difference form (wave-uniform branch, rare for unrelated frames)
+                    bool any = false;
 #pragma unroll
-                for (int c = 0; c < C; ++c) d[c] = (PIPE && c < C - 1) ? dn[c] : frame_dist<D>(xs[xa], yf[(r + c) % S]);
-                if (PIPE) {
+                    for (int c = 0; c < C; ++c) {
+                        float sc;
+                        d[c] = frame_sq_expanded<D>(xs[xa], yf[(r + c) % S], sc);
+                        any |= d[c] < sc * L.tau;
+                    }
+                    if (__ballot(any) != 0ull) {
 #pragma unroll
-                    for (int c = 0; c < C - 1; ++c) dn[c] = frame_dist<D>(xs[xb], yf[(r + 1 + c) % S]);
+                        for (int c = 0; c < C; ++c) {
+                            const float sc = xs[xa][D] + yf[(r + c) % S][D];
+                            const float ex = frame_sq_exact<D>(xs[xa], yf[(r + c) % S]);
+                            d[c] = (d[c] < sc * L.tau) ? ex : d[c];
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < C; ++c) d[c] = (APD_ABLATE & 1) ? d[c] : __builtin_amdgcn_sqrtf(d[c]);
+                    read_row(xs[0], tau + 1 - gl);                // the row frame is dead now: fetch the next one under the DP rows
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) d[c] = (PIPE && c < C - 1) ? dn[c] : frame_dist<D, DN>(xs[xa], yf[(r + c) % S]);
+                    if (PIPE) {
+#pragma unroll
+                        for (int c = 0; c < C - 1; ++c) dn[c] = frame_dist<D, DN>(xs[xb], yf[(r + 1 + c) % S]);
+                    }
                 }
                 // the two DP rows
                 float left1 = group_from_lower<G>(prev1[C - 1], APD_INF, gl);
@@ -264,7 +313,7 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                 }
                 // advance the column window: every column moves one lane down
 #pragma unroll
-                for (int k = 0; k < D; ++k) {
+                for (int k = 0; k < (HYBRID ? DN : D); ++k) {
                     if (APD_ABLATE & 4) { yf[e][k] = yf[(r + 1) % S][k] + yf[e][k]; continue; }
                     yf[e][k] = group_from_upper<G>(yf[(r + 1) % S][k], yf[e][k], gl);
                 }
@@ -294,14 +343,20 @@ static void launch_systolic_cg(const AlignLaunch &L, bool uniform, hipStream_t s
     constexpr int WPT = kSlotsPerTile / (4 * PPW);
     const uint32_t tiles8 = (L.n_tiles + 7u) / 8u * 8u;
     const dim3 grid(tiles8 * WPT), block(256);
-    if (uniform) hipLaunchKernelGGL((dtw_fused_systolic<D, C, G, true>), grid, block, 0, stream, L);
-    else hipLaunchKernelGGL((dtw_fused_systolic<D, C, G, false>), grid, block, 0, stream, L);
+    if (L.hybrid) {
+        if (uniform) hipLaunchKernelGGL((dtw_fused_systolic<D, C, G, true, true>), grid, block, 0, stream, L);
+        else hipLaunchKernelGGL((dtw_fused_systolic<D, C, G, false, true>), grid, block, 0, stream, L);
+    } else {
+        if (uniform) hipLaunchKernelGGL((dtw_fused_systolic<D, C, G, true, false>), grid, block, 0, stream, L);
+        else hipLaunchKernelGGL((dtw_fused_systolic<D, C, G, false, false>), grid, block, 0, stream, L);
+    }
 }
 
 template <int D>
 bool launch_systolic(const AlignLaunch &L, int g, int c, bool uniform, hipStream_t stream)
 {
-#define APD_CASE(GG, CC) if (g == GG && c == CC) { launch_systolic_cg<D, CC, GG>(L, uniform, stream); return true; }
+    // C = 9 keeps 10 column frames per lane in registers: only for D <= 16 (D = 26 would spill)
+#define APD_CASE(GG, CC) if constexpr (CC < 9 || D <= 16) { if (g == GG && c == CC) { launch_systolic_cg<D, CC, GG>(L, uniform, stream); return true; } }
     APD_CASE(8, 9)
     APD_CASE(16, 2) APD_CASE(16, 3) APD_CASE(16, 5) APD_CASE(16, 9)
     APD_CASE(64, 3) APD_CASE(64, 5) APD_CASE(64, 9)

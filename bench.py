@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per leg (0 = skip)")
     ap.add_argument("--verify", type=int, default=64, help="entries re-checked against the oracle after timing")
+    ap.add_argument("--distance", default="hybrid", choices=["hybrid", "exact"], help="local-distance form (apd_set_distance_mode)")
+    ap.add_argument("--tau", type=float, default=0.0, help="hybrid recomputation threshold (0 = library default 1/64)")
     ap.add_argument("--cluster", action="store_true", help="also time percentile + UPGMA (rank 0, outside the timed region)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (staged through host memory) only to rehearse N>1 on a box with fewer GPUs")
@@ -136,6 +138,7 @@ def main():
     ctx = _lib.Context(dev_index, stream=torch.cuda.current_stream().cuda_stream)
     ctx.selftest()
     ctx.set_variant(args.variant)
+    ctx.set_distance_mode(args.distance, args.tau)
     ctx.set_timing(True)
     d_frames = torch.from_numpy(frames).to(dev)                      # inputs resident in HBM
     off_c = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -212,7 +215,7 @@ def main():
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "n_seq": n, "nominal_len": wl["length"],
                        "dim": dim, "warping_band_percentage": wl["pct"], "ordered_pairs": pairs_all,
                        "cells_per_step": cells_all, "sharding": "pair tiles 16x16, cyclic over %d ranks, 1 all-gather" % world,
-                       "kernel_variant": args.variant},
+                       "kernel_variant": args.variant, "distance_form": args.distance},
             "wall_clock_matrix_s": elapsed / args.steps,
             "pairs_per_s": pairs_all * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -40,8 +40,11 @@ def assert_parity(got, want, rtol=RTOL):
 
 
 def gpu_align_all(ctx, frames, offsets, dim, pct, ins=1.0, dele=1.0, mat=1.0, variant=0):
+    """variant 0: production kernel, hybrid distances; 1: generic kernel; 2: production kernel, difference-form distances."""
     from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
     from audio_pattern_discovery_amd.discovery import Discovery
+    ctx.set_distance_mode("exact" if variant == 2 else "hybrid")
+    variant = 0 if variant == 2 else variant
     ctx.set_variant(variant)
     seqs = [NDSequence(s.reshape(-1, dim)) for s in synth.split(frames, offsets)]
     w = AlignmentWorkers.new(seqs, ctx)
@@ -56,7 +59,7 @@ def test_selftest_cross_lane_primitives(ctx):
     ctx.selftest()
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "*.npz"))))
 def test_golden_vectors(ctx, path, variant):
     g = np.load(path)
@@ -68,7 +71,7 @@ def test_golden_vectors(ctx, path, variant):
     assert_parity(got, g["dist"])
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("dim,pct,n_seq,length,jitter,integer,pens", [
     (13, 0.0625, 40, 96, 3, False, (1, 1, 1)),        # band binds, w = band + 2
     (13, 0.0625, 24, 200, 40, False, (1, 1, 1)),      # |n-m| > band: widening (alignments.rs:173)
@@ -229,3 +232,24 @@ def test_full_size_properties_cfg3(ctx, oracle):
     _lib.check(L.apd_unpack_tiles_async(ctx.handle, n, world, C.c_void_p(gathered.data_ptr()), C.c_void_p(out2.data_ptr())), ctx.handle)
     ctx.synchronize()
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("scale", [0.0, 1e-4, 1e-3, 1e-2, 0.1, 0.5, 2.0])
+def test_near_duplicates_hybrid_distance_accuracy(ctx, oracle, scale):
+    """The norm-expansion distance loses digits where frames nearly coincide; those cells are recomputed in the
+    difference form.  Sequences that are copies of each other up to noise of every magnitude must stay within
+    tolerance, and exact copies must score exactly 0."""
+    rng = np.random.default_rng(17)
+    base = synth.make_sequences(6, 120, 13, seed=5, copies=0.0)
+    frames, offsets = base
+    seqs = synth.split(frames, offsets)
+    noisy = [s + scale * rng.standard_normal(s.shape).astype(np.float32) for s in seqs]
+    offs = [s + np.float32(50.0) for s in seqs[:2]]                      # large common offset: cancellation everywhere
+    allseq = seqs + noisy + offs + [o + scale * rng.standard_normal(o.shape).astype(np.float32) for o in offs]
+    f2 = np.concatenate(allseq).astype(np.float32)
+    o2 = np.concatenate([[0], np.cumsum([len(s) for s in allseq])]).astype(np.uint64)
+    want = oracle.align_all(f2, o2, 0.0625, workers=8)
+    got = gpu_align_all(ctx, f2, o2, 13, 0.0625, variant=0)
+    assert_parity(got, want)
+    if scale == 0.0:
+        assert got[0, 6] == 0.0 and got[6, 0] == 0.0 and got[12, 14] == 0.0

@@ -3,7 +3,7 @@
 wl=$1; steps=$2; shift 2
 mkdir -p gpurun_out
 for v in "$@"; do
-  timeout -k 10 300 python bench.py --workload $wl --steps $steps --warmup 1 --cpu-seconds 0 --variant $v > gpurun_out/bench_${wl}_v$v.log 2>&1
+  timeout -k 10 300 python bench.py --workload $wl --steps $steps --warmup 1 --cpu-seconds 0 --variant $v $APD_BENCH_EXTRA > gpurun_out/bench_${wl}_v$v.log 2>&1
   rc=$?
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "variant $v TIMEOUT"; exit 1; fi
   python - <<PY
