@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     const uint32_t a_off = (uint32_t)(P.A - L.d_frames) * 4u, b_off = (uint32_t)(P.B - L.d_frames) * 4u;   // bytes
     constexpr uint32_t FB = DP * 4u;                             // bytes per padded frame
     float ins = L.band.ins, del = L.band.del, mat = L.band.mat;
-    asm volatile("" : "+v"(ins), "+v"(del), "+v"(mat));       // keep the penalties in VGPRs: an SGPR operand doubles the fma's issue cost
+    float tau_thr = L.tau;
+    asm volatile("" : "+v"(ins), "+v"(del), "+v"(mat), "+v"(tau_thr));   // keep them in VGPRs: an SGPR operand doubles a VOP2's issue cost
     // row-frame ring of this wave: slot = row & (R - 1); rows <= 0 hold -INF.  R > 2U + G - 2 keeps a refill from
     // overwriting a row some lane still needs.
     constexpr int R = (G == 64) ? 128 : 64;
@@ -261,14 +262,14 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                     for (int c = 0; c < C; ++c) {
                         float sc;
                         d[c] = frame_sq_expanded<D>(xs[xa], yf[(r + c) % S], sc);
-                        any |= d[c] < sc * L.tau;
+                        any |= d[c] < sc * tau_thr;
                     }
                     if (__ballot(any) != 0ull) {
 #pragma unroll
                         for (int c = 0; c < C; ++c) {
                             const float sc = xs[xa][D] + yf[(r + c) % S][D];
                             const float ex = frame_sq_exact<D>(xs[xa], yf[(r + c) % S]);
-                            d[c] = (d[c] < sc * L.tau) ? ex : d[c];
+                            d[c] = (d[c] < sc * tau_thr) ? ex : d[c];
                         }
                     }
 #pragma unroll
