@@ -60,7 +60,10 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ x
 // DCT-I as a K x K table product, drop 4, subtract the mean of what is left (spectrogram.rs:51-79).
 struct CepsParams {
     const int16_t *samples;
-    uint64_t n_samples, n_frames;
+    const uint64_t *sample_off;   // [n_seq+1] first sample of every recording
+    const uint64_t *frame_off;    // [n_seq+1] first output frame of every recording
+    uint32_t n_seq;
+    uint64_t n_frames;
     uint32_t fft, step, L, fstep, K, log2n;
     const float *hamming;      // [fft]
     const float *triag;        // [L]
@@ -80,7 +83,9 @@ __global__ __launch_bounds__(256) void cepstrum_kernel(const CepsParams P)
     float *mag = base + 4 * N, *conv = mag + half, *ceps = conv + P.K;
     const uint64_t frame = (uint64_t)blockIdx.x * 4 + wave;
     const bool live = frame < P.n_frames;
-    const uint64_t start = live ? frame * P.step : 0;             // i - fft_size with i = fft + frame * step (:51-53)
+    uint32_t lo = 0, hi = P.n_seq;                                // recording holding this frame: largest s with frame_off[s] <= frame
+    while (live && hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (P.frame_off[mid] <= frame) lo = mid; else hi = mid; }
+    const uint64_t start = live ? P.sample_off[lo] + (frame - P.frame_off[lo]) * P.step : 0;   // i - fft_size, i = fft + t * step (:51-53)
     for (uint32_t s = lane; s < N; s += 64) {
         const float v = live ? (float)P.samples[start + s] * P.hamming[s] : 0.0f;   // :55-59
         bufa[s] = make_float2(v, 0.0f);
@@ -165,19 +170,24 @@ extern "C" int apd_encode(apd_context *ctx, const float *x, uint64_t t, uint32_t
     return rc;
 }
 
-extern "C" int apd_cepstrum(apd_context *ctx, const int16_t *samples, uint64_t n_samples, uint32_t fft_size,
-                            uint32_t fft_step, uint32_t filter_size, int on_device, float *out, uint64_t *n_frames,
-                            uint32_t *n_bins)
+static int cepstrum_impl(apd_context *ctx, const int16_t *samples, const uint64_t *sample_off, uint32_t n_seq, uint32_t fft_size,
+                         uint32_t fft_step, uint32_t filter_size, int on_device, float *out, uint64_t *frame_off, uint32_t *n_bins)
 {
-    if (!ctx || !n_frames || !n_bins || fft_size < 2 || fft_step == 0 || filter_size == 0) return APD_ERR_INVALID_ARG;
+    if (!ctx || !sample_off || !frame_off || !n_bins || fft_size < 2 || fft_step == 0 || filter_size == 0) return APD_ERR_INVALID_ARG;
     const uint32_t L = fft_size / filter_size, half = fft_size / 2, fstep = L / 2;      // spectrogram.rs:38,64,67
     if (L == 0 || fstep == 0) return APD_ERR_INVALID_ARG;                               // step_by(0) panics in the reference
     uint32_t K = 0;
     for (uint32_t i = L; i < half; i += fstep) ++K;                                     // numerics.rs:105
     if (K < 5) return APD_ERR_INVALID_ARG;                                              // cepstrum[4..] of an empty tail
-    uint64_t T = 0;
-    for (uint64_t i = fft_size; i < n_samples; i += fft_step) ++T;                      // spectrogram.rs:51
-    *n_frames = T; *n_bins = K - 4;
+    frame_off[0] = 0;
+    for (uint32_t s = 0; s < n_seq; ++s) {
+        if (sample_off[s + 1] < sample_off[s]) return APD_ERR_INVALID_ARG;
+        const uint64_t n = sample_off[s + 1] - sample_off[s];
+        const uint64_t t = n > fft_size ? (n - fft_size + fft_step - 1) / fft_step : 0; // i in (fft_size..n).step_by(step), spectrogram.rs:51
+        frame_off[s + 1] = frame_off[s] + t;
+    }
+    const uint64_t T = frame_off[n_seq], n_samples = sample_off[n_seq];
+    *n_bins = K - 4;
     if (!out || T == 0) return APD_OK;
     if (!samples) return APD_ERR_INVALID_ARG;
     uint32_t log2n = 0;
@@ -207,18 +217,23 @@ extern "C" int apd_cepstrum(apd_context *ctx, const int16_t *samples, uint64_t n
         const double a = -2.0 * M_PI * (double)k / (double)fft_size;
         tw[k] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
-    const size_t tab_bytes = tab.size() * sizeof(float);
+    const size_t tab_bytes = tab.size() * sizeof(float), off_bytes = 2 * ((size_t)n_seq + 1) * sizeof(uint64_t);
     char *pool = nullptr;
     const size_t in_bytes = on_device ? 0 : n_samples * sizeof(int16_t), out_bytes = on_device ? 0 : T * (K - 4) * sizeof(float);
-    const size_t in_off = (tab_bytes + 255) & ~(size_t)255, out_off = (in_off + in_bytes + 255) & ~(size_t)255;
+    const size_t offs_off = (tab_bytes + 255) & ~(size_t)255, in_off = (offs_off + off_bytes + 255) & ~(size_t)255,
+                 out_off = (in_off + in_bytes + 255) & ~(size_t)255;
     HIP_TRY(ctx, hipMalloc((void **)&pool, out_off + out_bytes + 256));
     int rc = APD_OK;
     auto guard = [&](hipError_t e) { if (e != hipSuccess && rc == APD_OK) { ctx->last_error = hipGetErrorString(e); rc = APD_ERR_HIP; } };
     guard(hipMemcpyAsync(pool, tab.data(), tab_bytes, hipMemcpyHostToDevice, ctx->stream));
+    guard(hipMemcpyAsync(pool + offs_off, sample_off, off_bytes / 2, hipMemcpyHostToDevice, ctx->stream));
+    guard(hipMemcpyAsync(pool + offs_off + off_bytes / 2, frame_off, off_bytes / 2, hipMemcpyHostToDevice, ctx->stream));
     if (!on_device) guard(hipMemcpyAsync(pool + in_off, samples, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     CepsParams P{};
     P.samples = on_device ? samples : reinterpret_cast<const int16_t *>(pool + in_off);
-    P.n_samples = n_samples; P.n_frames = T; P.fft = fft_size; P.step = fft_step; P.L = L; P.fstep = fstep; P.K = K; P.log2n = log2n;
+    P.sample_off = reinterpret_cast<const uint64_t *>(pool + offs_off);
+    P.frame_off = P.sample_off + n_seq + 1;
+    P.n_seq = n_seq; P.n_frames = T; P.fft = fft_size; P.step = fft_step; P.L = L; P.fstep = fstep; P.K = K; P.log2n = log2n;
     const float *d_tab = reinterpret_cast<const float *>(pool);
     P.hamming = d_tab; P.triag = d_tab + fft_size; P.dct = d_tab + fft_size + L;
     P.twiddle = reinterpret_cast<const float2 *>(d_tab + fft_size + L + (size_t)K * K);
@@ -235,4 +250,23 @@ extern "C" int apd_cepstrum(apd_context *ctx, const int16_t *samples, uint64_t n
     guard(hipStreamSynchronize(ctx->stream));
     hipFree(pool);
     return rc;
+}
+
+extern "C" int apd_cepstrum(apd_context *ctx, const int16_t *samples, uint64_t n_samples, uint32_t fft_size,
+                            uint32_t fft_step, uint32_t filter_size, int on_device, float *out, uint64_t *n_frames,
+                            uint32_t *n_bins)
+{
+    if (!n_frames) return APD_ERR_INVALID_ARG;
+    const uint64_t sample_off[2] = {0, n_samples};
+    uint64_t frame_off[2] = {0, 0};
+    const int rc = cepstrum_impl(ctx, samples, sample_off, 1, fft_size, fft_step, filter_size, on_device, out, frame_off, n_bins);
+    *n_frames = frame_off[1];
+    return rc;
+}
+
+extern "C" int apd_cepstrum_batch(apd_context *ctx, const int16_t *samples, const uint64_t *sample_offsets, uint32_t n_seq,
+                                  uint32_t fft_size, uint32_t fft_step, uint32_t filter_size, int on_device, float *out,
+                                  uint64_t *frame_offsets, uint32_t *n_bins)
+{
+    return cepstrum_impl(ctx, samples, sample_offsets, n_seq, fft_size, fft_step, filter_size, on_device, out, frame_offsets, n_bins);
 }

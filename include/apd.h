@@ -167,6 +167,14 @@ int apd_cepstrum(apd_context *ctx, const int16_t *samples, uint64_t n_samples, u
                  uint32_t fft_step, uint32_t filter_size, int on_device, float *out, uint64_t *n_frames,
                  uint32_t *n_bins);
 
+/* The same for n_seq recordings stored back to back (sample_offsets: n_seq+1): one launch for the whole corpus.
+ * frame_offsets (n_seq+1, host, always written) and out ([frame_offsets[n_seq]][*n_bins], packed) are exactly the
+ * `offsets` / `frames` arguments of apd_batch_create, so with on_device != 0 features go from audio to the
+ * alignment without leaving HBM.  out may be NULL to query sizes. */
+int apd_cepstrum_batch(apd_context *ctx, const int16_t *samples, const uint64_t *sample_offsets, uint32_t n_seq,
+                       uint32_t fft_size, uint32_t fft_step, uint32_t filter_size, int on_device, float *out,
+                       uint64_t *frame_offsets, uint32_t *n_bins);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,3 +88,50 @@ def test_cepstrum_unsupported_window(ctx, apd):
     with pytest.raises(apd.ApdError) as e:
         NDSequence.new(300, 128, 18, synth.make_audio(2000, seed=1), ctx)     # not a power of two
     assert e.value.status == apd.APD_ERR_UNSUPPORTED
+
+
+def test_audio_to_clusters_on_device(ctx, oracle, apd):
+    """cfg 5's data path at toy size, everything resident in HBM: i16 audio of many recordings -> apd_cepstrum_batch ->
+    apd_encode -> apd_batch_create(frames_on_device) -> align_all, against the oracle pipeline (main.rs:150-161 then
+    187-195).  Cepstrum parity is unpinned (see module docstring): DTW costs agree to 1e-3."""
+    import ctypes as C
+    import torch
+    L = apd.lib()
+    rng = np.random.default_rng(5)
+    lens = rng.integers(256 + 128 * 20, 256 + 128 * 40, size=12)
+    audio = [synth.make_audio(int(n), seed=100 + i) for i, n in enumerate(lens)]
+    audio[7] = audio[2].copy()                                             # a repeated recording: distance exactly 0
+    samples = np.concatenate(audio)
+    s_off = np.concatenate([[0], np.cumsum([len(a) for a in audio])]).astype(np.uint64)
+    w = ((rng.random((13, 8)) - 0.5) / 8).astype(np.float32)
+    b = ((rng.random(8) - 0.5) / 8).astype(np.float32)
+    n = len(audio)
+    d_samples = torch.from_numpy(samples).cuda()
+    f_off = np.zeros(n + 1, dtype=np.uint64)
+    nb = C.c_uint32(0)
+    u64p = C.POINTER(C.c_uint64)
+    apd.check(L.apd_cepstrum_batch(ctx.handle, C.c_void_p(d_samples.data_ptr()), s_off.ctypes.data_as(u64p), n, 256, 128, 18, 1,
+                                   None, f_off.ctypes.data_as(u64p), C.byref(nb)), ctx.handle)
+    assert nb.value == 13
+    total = int(f_off[-1])
+    d_ceps = torch.empty(total * 13, dtype=torch.float32, device="cuda")
+    apd.check(L.apd_cepstrum_batch(ctx.handle, C.c_void_p(d_samples.data_ptr()), s_off.ctypes.data_as(u64p), n, 256, 128, 18, 1,
+                                   C.c_void_p(d_ceps.data_ptr()), f_off.ctypes.data_as(u64p), C.byref(nb)), ctx.handle)
+    d_lat = torch.empty(total * 8, dtype=torch.float32, device="cuda")
+    f32p = C.POINTER(C.c_float)
+    apd.check(L.apd_encode(ctx.handle, C.c_void_p(d_ceps.data_ptr()), total, 13, w.ctypes.data_as(f32p), b.ctypes.data_as(f32p), 8, 1,
+                           C.c_void_p(d_lat.data_ptr())), ctx.handle)
+    batch = C.c_void_p()
+    apd.check(L.apd_batch_create(ctx.handle, C.c_void_p(d_lat.data_ptr()), f_off.ctypes.data_as(u64p), n, 8, 1, C.byref(batch)), ctx.handle)
+    cfg = apd.AlignConfig(0.0625, 1, 1, 1)
+    got = np.empty((n, n), dtype=np.float32)
+    apd.check(L.apd_align_all(ctx.handle, batch, C.byref(cfg), got.ctypes.data_as(f32p)), ctx.handle)
+    L.apd_batch_destroy(batch)
+    # oracle pipeline
+    feats = [oracle.encode(oracle.cepstrum(a, 256, 128, 18), w, b) for a in audio]
+    assert [len(f) for f in feats] == np.diff(f_off).astype(int).tolist()
+    want = oracle.align_all(np.concatenate(feats), f_off, 0.0625, workers=4)
+    np.testing.assert_allclose(d_ceps.cpu().numpy().reshape(total, 13), np.concatenate([oracle.cepstrum(a, 256, 128, 18) for a in audio]),
+                               rtol=0, atol=3e-4)
+    assert got[2, 7] == 0.0 and got[7, 2] == 0.0
+    np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-5)
