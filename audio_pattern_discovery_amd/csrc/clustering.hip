@@ -8,10 +8,10 @@
 //   are recomputed from the raw distances in EXACTLY the reference's order (x ascending over Cp, y ascending over Cq,
 //   one running f32 accumulator, clustering.rs:157-169) from sorted member lists, so every linkage -- and with it the
 //   whole merge sequence, including the p/q order of mathematically tied directed pairs that the reference settles
-//   by rounding noise -- is bit-identical to the literal algorithm.  Each merge is three launches: a grid-wide
-//   arg-min over the live ordered pairs (HBM-bound: one read of the live part of S), one workgroup that reduces the
-//   candidates, applies merge_clusters and merges the two member lists, and one pass that rebuilds the new cluster's
-//   row and column.  Exact ties resolve to the lowest (id_p, id_q): what the reference does when its HashSet happens
+//   by rounding noise -- is bit-identical to the literal algorithm.  Each merge is three launches: row minima (a
+//   cached best ordered pair per live row; only rows whose cache went stale re-read their row of S), one workgroup
+//   that reduces the row minima, applies merge_clusters and merges the two member lists, and one pass that rebuilds
+//   the new cluster's row and column and patches the other rows' caches.  Exact ties resolve to the lowest (id_p, id_q): what the reference does when its HashSet happens
 //   to iterate in ascending order (clustering.rs:180-187); any other order is equally "reference".
 #include <algorithm>
 #include <cmath>
@@ -130,7 +130,9 @@ struct UpgmaState {
     uint32_t *id;             // [n] cluster id held by the slot
     uint32_t *live;           // [n_live] slots still holding a root, ascending slot order is irrelevant
     uint32_t *n_live;
-    Cand *cand;               // [n_blocks]
+    Cand *rbest;              // [n] cached best ordered pair of the row held by a slot
+    uint32_t *rscan;          // [n] 1: the cache of this row is stale, rescan it
+    uint32_t *last_sq;        // slot that died in the latest merge
     apd_cluster_op *ops;      // [n]
     uint32_t *n_ops;
     uint32_t *done;           // set once the loop condition of clustering.rs:104 fails
@@ -138,44 +140,50 @@ struct UpgmaState {
     uint32_t n;
 };
 
-// One workgroup per few live rows: scan the live columns, keep the best ordered pair of the block.
-__global__ __launch_bounds__(256) void upgma_argmin_kernel(UpgmaState st)
+// Row minima: one workgroup per live row whose cached best pair is stale (new cluster, or its best column just
+// merged/died); the others keep their cache.  A full scan reads one row of S: the per-merge HBM traffic is
+// (stale rows) x 4c bytes instead of 4c^2.
+__global__ __launch_bounds__(256) void upgma_rowmin_kernel(UpgmaState st)
 {
     __shared__ Cand red[256];
-    Cand best{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0};
-    if (*st.done == 0) {
-        const uint32_t nl = *st.n_live;
-        for (uint32_t r = blockIdx.x; r < nl; r += gridDim.x) {
-            const uint32_t sp = st.live[r];
-            const float size_p = st.size[sp];
-            const uint32_t idp = st.id[sp];
-            const float *row = st.S + (uint64_t)sp * st.n;
-            for (uint32_t c = threadIdx.x; c < nl; c += blockDim.x) {
-                const uint32_t sq = st.live[c];
-                if (sq == sp) continue;                                   // target_i != target_j (clustering.rs:182)
-                const float denom = size_p * st.size[sq];                 // size_x * size_y (:169)
-                const Cand cnd{row[sq] / denom, idp, st.id[sq], sp, sq};
-                if (better(cnd, best)) best = cnd;
-            }
+    if (*st.done != 0) return;
+    const uint32_t nl = *st.n_live;
+    for (uint32_t r = blockIdx.x; r < nl; r += gridDim.x) {
+        const uint32_t sp = st.live[r];
+        if (st.rscan[sp] == 0) continue;                                  // block-uniform
+        Cand best{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu, sp, sp};
+        const float size_p = st.size[sp];
+        const uint32_t idp = st.id[sp];
+        const float *row = st.S + (uint64_t)sp * st.n;
+        for (uint32_t c = threadIdx.x; c < nl; c += blockDim.x) {
+            const uint32_t sq = st.live[c];
+            if (sq == sp) continue;                                       // target_i != target_j (clustering.rs:182)
+            const float denom = size_p * st.size[sq];                     // size_x * size_y (:169)
+            const Cand cnd{row[sq] / denom, idp, st.id[sq], sp, sq};
+            if (better(cnd, best)) best = cnd;
         }
-    }
-    red[threadIdx.x] = best;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s && better(red[threadIdx.x + s], red[threadIdx.x])) red[threadIdx.x] = red[threadIdx.x + s];
+        red[threadIdx.x] = best;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s && better(red[threadIdx.x + s], red[threadIdx.x])) red[threadIdx.x] = red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { st.rbest[sp] = red[0]; st.rscan[sp] = 0; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) st.cand[blockIdx.x] = red[0];
 }
 
 // One workgroup: final arg-min, merge_clusters (clustering.rs:134-141), sums of the new cluster, the op record.
-__global__ __launch_bounds__(1024) void upgma_merge_kernel(UpgmaState st, uint32_t n_cand)
+__global__ __launch_bounds__(1024) void upgma_merge_kernel(UpgmaState st)
 {
     __shared__ Cand red[1024];
     __shared__ Cand win;
     if (*st.done != 0) return;
     Cand best{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0};
-    for (uint32_t c = threadIdx.x; c < n_cand; c += blockDim.x) if (better(st.cand[c], best)) best = st.cand[c];
+    {
+        const uint32_t nl0 = *st.n_live;
+        for (uint32_t c = threadIdx.x; c < nl0; c += blockDim.x) { const Cand cc = st.rbest[st.live[c]]; if (better(cc, best)) best = cc; }
+    }
     red[threadIdx.x] = best;
     __syncthreads();
     for (int s = 512; s > 0; s >>= 1) {
@@ -212,6 +220,13 @@ __global__ __launch_bounds__(1024) void upgma_merge_kernel(UpgmaState st, uint32
             out[(from_p ? i : i - cp) + lo] = v;
         }
     }
+    // drop sq from the live list (its order is irrelevant): every thread scans a stride, the finder swaps in the tail
+    {
+        const uint32_t tail = st.live[nl - 1];
+        __syncthreads();
+        for (uint32_t c = threadIdx.x; c < nl; c += blockDim.x)
+            if (st.live[c] == w.sq) st.live[c] = tail;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t op;
@@ -226,25 +241,24 @@ __global__ __launch_bounds__(1024) void upgma_merge_kernel(UpgmaState st, uint32
         st.id[w.sp] = k;
         const uint32_t used = *st.pool_used, cnt = st.mcount[w.sp] + st.mcount[w.sq];
         st.mstart[w.sp] = used; st.mcount[w.sp] = cnt; *st.pool_used = used + cnt;
-        *st.last_sp = w.sp;
-        // drop sq from the live list (order of the list is irrelevant)
-        uint32_t pos = 0;
-        while (st.live[pos] != w.sq) ++pos;
-        st.live[pos] = st.live[nl - 1];
+        *st.last_sp = w.sp; *st.last_sq = w.sq;
+        st.rscan[w.sp] = 1;                                               // the new cluster's row is new
         *st.n_live = nl - 1;
         if (nl - 1 <= 1 || !(w.l < st.threshold)) *st.done = 1;           // while n_clusters > 1 && distance < threshold (:104)
     }
 }
 
 // Row and column of the cluster created by the latest merge, summed exactly as linkage() does
-// (clustering.rs:157-169): x ascending, y ascending, one f32 accumulator.  One thread per (other cluster, direction).
-__global__ __launch_bounds__(128) void upgma_update_kernel(UpgmaState st)
+// (clustering.rs:157-169): x ascending, y ascending, ONE f32 accumulator -- the order is the contract, so the sum
+// cannot be a tree.  One wavefront per (other cluster, direction): the 64 lanes gather 64 distances at a time, then
+// the accumulator walks them in order (v_readlane + add), ~100x faster than one thread chasing dependent loads.
+__global__ __launch_bounds__(256) void upgma_update_kernel(UpgmaState st)
 {
     const uint32_t sp = *st.last_sp;
     if (sp == 0xFFFFFFFFu || *st.done != 0) return;                      // nothing merged, or no further arg-min will run
     const uint32_t nl = *st.n_live;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t c = t >> 1, dir = t & 1u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const uint32_t c = wave >> 1, dir = wave & 1u;
     if (c >= nl) return;
     const uint32_t s = st.live[c];
     if (s == sp) return;
@@ -253,9 +267,24 @@ __global__ __launch_bounds__(128) void upgma_update_kernel(UpgmaState st)
     float acc = 0.0f;
     for (uint32_t a = 0; a < cx; ++a) {
         const float *row = st.d + (uint64_t)lx[a] * st.n;
-        for (uint32_t b = 0; b < cy; ++b) acc = acc + row[ly[b]];
+        for (uint32_t b0 = 0; b0 < cy; b0 += 64) {
+            const uint32_t cnt = min(64u, cy - b0);
+            const float v = (lane < cnt) ? row[ly[b0 + lane]] : 0.0f;
+            for (uint32_t t = 0; t < cnt; ++t)
+                acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t));
+        }
     }
-    if (dir) st.S[(uint64_t)s * st.n + sp] = acc; else st.S[(uint64_t)sp * st.n + s] = acc;
+    if (lane != 0) return;
+    if (dir) {
+        st.S[(uint64_t)s * st.n + sp] = acc;
+        // row s: its cached best pair survives unless it pointed at one of the two merged slots; the new entry may beat it
+        const Cand old = st.rbest[s];
+        if (old.sq == sp || old.sq == *st.last_sq) st.rscan[s] = 1;
+        else {
+            const Cand cnd{acc / (st.size[s] * st.size[sp]), st.id[s], st.id[sp], s, sp};
+            if (better(cnd, old)) st.rbest[s] = cnd;
+        }
+    } else st.S[(uint64_t)sp * st.n + s] = acc;
 }
 
 __global__ void upgma_init_S_kernel(UpgmaState st)
@@ -268,7 +297,7 @@ __global__ void upgma_init_S_kernel(UpgmaState st)
 __global__ void upgma_init_kernel(UpgmaState st)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < st.n) { st.size[i] = 1.0f; st.id[i] = i; st.live[i] = i; st.pool[i] = i; st.mstart[i] = i; st.mcount[i] = 1; }   // parents = [0..n) (:88-91)
+    if (i < st.n) { st.size[i] = 1.0f; st.id[i] = i; st.live[i] = i; st.pool[i] = i; st.mstart[i] = i; st.mcount[i] = 1; st.rscan[i] = 1; }   // parents = [0..n) (:88-91)
     if (i == 0) {
         *st.n_live = st.n;
         *st.n_ops = 0;
@@ -311,12 +340,12 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
 
     UpgmaState st{};
     st.n = n;
-    const int n_blocks = (int)std::min<uint32_t>(n, 1024);
+    const int n_blocks = (int)std::min<uint32_t>(n, 4096);
     char *pool = nullptr;
     const size_t bytes_S = nn * sizeof(float), bytes_f = (size_t)n * sizeof(float), bytes_u = (size_t)n * sizeof(uint32_t);
     const size_t bytes_lists = ((size_t)n * (n + 1) / 2 + n) * sizeof(uint32_t);    // every merged list is appended once
     const size_t bytes_d = distances_on_device ? 0 : bytes_S;
-    const size_t total = bytes_S + bytes_d + bytes_lists + bytes_f + 4 * bytes_u + n_blocks * sizeof(Cand) +
+    const size_t total = bytes_S + bytes_d + bytes_lists + bytes_f + 5 * bytes_u + (size_t)n * sizeof(Cand) +
                          (size_t)n * sizeof(apd_cluster_op) + 256;
     HIP_TRY(ctx, hipMalloc((void **)&pool, total));
     size_t off = 0;
@@ -328,11 +357,12 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     st.live = (uint32_t *)(pool + off); off += bytes_u;
     st.mstart = (uint32_t *)(pool + off); off += bytes_u;
     st.mcount = (uint32_t *)(pool + off); off += bytes_u;
-    st.cand = (Cand *)(pool + off); off += n_blocks * sizeof(Cand);
+    st.rscan = (uint32_t *)(pool + off); off += bytes_u;
+    st.rbest = (Cand *)(pool + off); off += (size_t)n * sizeof(Cand);
     st.ops = (apd_cluster_op *)(pool + off); off += (size_t)n * sizeof(apd_cluster_op);
     off = (off + 63) & ~(size_t)63;
     st.n_live = (uint32_t *)(pool + off); st.n_ops = st.n_live + 1; st.done = st.n_live + 2;
-    st.pool_used = st.n_live + 3; st.last_sp = st.n_live + 4;
+    st.pool_used = st.n_live + 3; st.last_sp = st.n_live + 4; st.last_sq = st.n_live + 5;
     auto fail = [&](int rc) { hipFree(pool); return rc; };
     if (distances_on_device) st.d = distances;
     else {
@@ -351,19 +381,38 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     hipLaunchKernelGGL(upgma_init_S_kernel, dim3((unsigned)std::min<uint64_t>((nn + 255) / 256, 8192)), dim3(256), 0, ctx->stream, st);
     hipLaunchKernelGGL(upgma_init_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, st);
     uint32_t host_state[3] = {n, 0, 0};                                   // n_live, n_ops, done
-    const uint32_t batch = 32;                                            // merges enqueued between host checks
-    while (true) {
+    // The merge loop is launch-bound (three short dependent launches per merge): a batch of merges is captured once into a
+    // hipGraph and replayed until the device-side `done` flag rises; kernels launched after that return immediately.
+    const uint32_t batch = 64;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    auto enqueue_batch = [&]() {
         for (uint32_t b = 0; b < batch; ++b) {
-            hipLaunchKernelGGL(upgma_argmin_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, st);
-            hipLaunchKernelGGL(upgma_merge_kernel, dim3(1), dim3(1024), 0, ctx->stream, st, (uint32_t)n_blocks);
-            hipLaunchKernelGGL(upgma_update_kernel, dim3((2 * n + 127) / 128), dim3(128), 0, ctx->stream, st);
+            hipLaunchKernelGGL(upgma_rowmin_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, st);
+            hipLaunchKernelGGL(upgma_merge_kernel, dim3(1), dim3(1024), 0, ctx->stream, st);
+            hipLaunchKernelGGL(upgma_update_kernel, dim3((2 * n + 3) / 4), dim3(256), 0, ctx->stream, st);
         }
-        e = hipGetLastError();
+    };
+    auto drop_graph = [&]() { if (exec) hipGraphExecDestroy(exec); if (graph) hipGraphDestroy(graph); exec = nullptr; graph = nullptr; };
+    e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return fail(APD_ERR_HIP); }
+    // the legacy default stream cannot be captured: then the batch is enqueued directly
+    bool use_graph = ctx->stream != nullptr && hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (use_graph) {
+        enqueue_batch();
+        use_graph = hipStreamEndCapture(ctx->stream, &graph) == hipSuccess && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (!use_graph) drop_graph();
+    }
+    (void)hipGetLastError();
+    while (true) {
+        if (use_graph) e = hipGraphLaunch(exec, ctx->stream);
+        else { enqueue_batch(); e = hipGetLastError(); }
         if (e == hipSuccess) e = hipMemcpyAsync(host_state, st.n_live, sizeof(host_state), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return fail(APD_ERR_HIP); }
+        if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); drop_graph(); return fail(APD_ERR_HIP); }
         if (host_state[2] != 0) break;
     }
+    drop_graph();
     const uint32_t cnt = host_state[1];
     std::vector<uint32_t> ids(n), live(host_state[0]);
     e = hipMemcpyAsync(ops, st.ops, (size_t)cnt * sizeof(apd_cluster_op), hipMemcpyDeviceToHost, ctx->stream);
