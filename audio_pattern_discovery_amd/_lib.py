@@ -88,6 +88,8 @@ SYMBOLS = [
     ("apd_cluster_sets", C.c_int, [C.POINTER(ClusterOp), C.c_uint32, _u32p, C.c_uint32, C.c_uint32, _u32p, _u32p,
                                    _u32p]),
     ("apd_encode", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, _f32p, _f32p, C.c_uint32, C.c_int, _vp]),
+    ("apd_interesting_ranges", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64, C.c_int, _u64p,
+                                         C.c_uint64, _u64p]),
     ("apd_cepstrum_batch", C.c_int, [_vp, _vp, _u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _vp, _u64p,
                                      _u32p]),
     ("apd_cepstrum", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _vp, _u64p,

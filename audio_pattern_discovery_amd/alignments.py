@@ -41,6 +41,17 @@ class NDSequence:
     def encoded(self, nn, ctx=None):        # spectrogram.rs:103-121
         return NDSequence(nn.predict_frames(self.frames, ctx), nn.n_latent(), self.audio_id)
 
+    def interesting_ranges(self, moving_average, perc, min_len, ctx=None):
+        """spectrogram.rs:192-216 -> list of Slice(start, stop)."""
+        ctx = ctx or _lib.default_context()
+        t = self.len()
+        ranges = np.zeros(2 * max(t, 1), dtype=np.uint64)
+        n = C.c_uint64(0)
+        _lib.check(_lib.lib().apd_interesting_ranges(ctx.handle, C.c_void_p(self.frames.ctypes.data), t, self.n_bins,
+                                                     int(moving_average), float(perc), int(min_len), 0,
+                                                     ranges.ctypes.data_as(C.POINTER(C.c_uint64)), t, C.byref(n)), ctx.handle)
+        return [Slice(int(ranges[2 * i]), int(ranges[2 * i + 1]), self) for i in range(n.value)]
+
     def vec(self, t):                       # spectrogram.rs:99-101
         return self.frames[t]
 
@@ -48,6 +59,20 @@ class NDSequence:
         return int(self.frames.shape[0])
 
     __len__ = len
+
+
+@dataclass
+class Slice:
+    """spectrogram.rs:222-243: a frame range of a sequence."""
+    start: int
+    stop: int
+    sequence: "NDSequence" = None
+
+    def len(self):
+        return self.stop - self.start
+
+    def extract(self):                      # spectrogram.rs:245-262
+        return NDSequence(self.sequence.frames[self.start:self.stop], self.sequence.n_bins, self.sequence.audio_id)
 
 
 @dataclass

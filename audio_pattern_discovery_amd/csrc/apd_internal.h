@@ -10,6 +10,7 @@
 
 #include "../../include/apd.h"
 
+struct apd_context;
 namespace apd {
 
 constexpr int kTile = 16;              // sequences per tile side -> 256 pair slots per tile
@@ -47,6 +48,10 @@ hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_of
 hipError_t launch_unpack(const float *d_gathered, float *d_out, uint32_t n_seq, uint32_t world,
                          uint64_t slab_floats, hipStream_t stream);
 hipError_t launch_selftest(int *d_result, hipStream_t stream);
+
+// numerics.rs:125-133 on a device array (clustering.hip): radix select of the k-th smallest non-NaN value.
+int device_select(apd_context *ctx, const float *d_x, uint64_t len, uint64_t k, float *value);
+uint64_t percentile_index(uint64_t len, float perc);
 
 // Host-side mirrors of the device band arithmetic (bit-identical f32 product).
 inline uint32_t host_band_from_pct(float pct, uint32_t len)

@@ -59,6 +59,9 @@ __global__ void select_hist_kernel(const float *__restrict__ x, uint64_t len, ui
         if (lh[t]) atomicAdd(&hist[t], (unsigned long long)lh[t]);
 }
 
+}  // namespace
+
+namespace apd {
 // numerics.rs:125-133 on a device array.  k = (len as f32 * perc) as usize is computed by the caller.
 int device_select(apd_context *ctx, const float *d_x, uint64_t len, uint64_t k, float *value)
 {
@@ -105,6 +108,9 @@ uint64_t percentile_index(uint64_t len, float perc)
     if (nf >= 18446744073709551616.0f) return UINT64_MAX;
     return (uint64_t)nf;
 }
+}  // namespace apd
+
+namespace {
 
 // ---------------------------------------------------------------------------------------- UPGMA
 

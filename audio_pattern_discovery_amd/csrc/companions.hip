@@ -2,6 +2,7 @@
 // NDSequence::new (src/spectrogram.rs:31-80).  Both are streaming kernels far off the hot path's critical time
 // (cfg 4: 4.2 M frames x 21 floats; cfg 5: 33.5 M frames of 256 samples); they exist so that the feature sequences
 // the alignment consumes are produced in HBM and never cross PCIe.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -132,7 +133,75 @@ __global__ __launch_bounds__(256) void cepstrum_kernel(const CepsParams P)
         for (uint32_t k = 4 + lane; k < P.K; k += 64) P.out[frame * (P.K - 4) + (k - 4)] = ceps[k] - mu;   // :75-79
 }
 
+// ------------------------------------------------------------------------------------------ VAT
+// NDSequence::variance (spectrogram.rs:174-187): per-frame population std (numerics.rs:12-29), then the mean of the k
+// PREVIOUS values, summed in order.
+__global__ void frame_std_kernel(const float *__restrict__ frames, uint64_t t, uint32_t n_bins, float *__restrict__ deltas)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float *v = frames + i * n_bins;
+        float mean = 0.0f;
+        for (uint32_t k = 0; k < n_bins; ++k) mean = mean + v[k];
+        mean = mean / (float)n_bins;
+        float sd = 0.0f;
+        for (uint32_t k = 0; k < n_bins; ++k) { const float d = v[k] - mean; sd = sd + d * d; }
+        deltas[i] = sqrtf(sd / (float)n_bins);
+    }
+}
+__global__ void moving_mean_kernel(const float *__restrict__ deltas, uint64_t t, uint32_t k, float *__restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t; i += (uint64_t)gridDim.x * blockDim.x) {
+        float acc = 0.0f;
+        if (i >= k) { for (uint32_t q = 0; q < k; ++q) acc = acc + deltas[i - k + q]; acc = acc / (float)k; }
+        out[i] = acc;
+    }
+}
+
 }  // namespace
+
+// NDSequence::interesting_ranges (spectrogram.rs:192-216)
+extern "C" int apd_interesting_ranges(apd_context *ctx, const float *frames, uint64_t t, uint32_t n_bins, uint32_t moving_average,
+                                      float perc, uint64_t min_len, int on_device, uint64_t *ranges, uint64_t capacity,
+                                      uint64_t *n_ranges)
+{
+    if (!ctx || !n_ranges || n_bins == 0 || (t && !frames) || (capacity && !ranges)) return APD_ERR_INVALID_ARG;
+    *n_ranges = 0;
+    const uint64_t kidx = apd::percentile_index(t, perc);
+    if (t == 0 || kidx >= t) return APD_ERR_INDEX;                      // percentile of an empty / too short vector panics (numerics.rs:132)
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    char *pool = nullptr;
+    const size_t in_bytes = on_device ? 0 : (size_t)t * n_bins * sizeof(float), v_bytes = ((size_t)t * sizeof(float) + 255) & ~(size_t)255;
+    HIP_TRY(ctx, hipMalloc((void **)&pool, 2 * v_bytes + in_bytes + 256));
+    float *d_deltas = (float *)pool, *d_var = (float *)(pool + v_bytes);
+    const float *d_frames = on_device ? frames : (const float *)(pool + 2 * v_bytes);
+    int rc = APD_OK;
+    auto guard = [&](hipError_t e) { if (e != hipSuccess && rc == APD_OK) { ctx->last_error = hipGetErrorString(e); rc = APD_ERR_HIP; } };
+    if (!on_device) guard(hipMemcpyAsync(pool + 2 * v_bytes, frames, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    const unsigned blocks = (unsigned)std::min<uint64_t>((t + 255) / 256, 8192);
+    if (rc == APD_OK) {
+        hipLaunchKernelGGL(frame_std_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_frames, t, n_bins, d_deltas);
+        hipLaunchKernelGGL(moving_mean_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_deltas, t, moving_average, d_var);
+        guard(hipGetLastError());
+    }
+    float th = 0.0f;
+    if (rc == APD_OK) rc = apd::device_select(ctx, d_var, t, kidx, &th);                    // :198
+    std::vector<float> var(t);
+    if (rc == APD_OK) guard(hipMemcpyAsync(var.data(), d_var, (size_t)t * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    guard(hipStreamSynchronize(ctx->stream));
+    hipFree(pool);
+    if (rc != APD_OK) return rc;
+    uint64_t start = 0, cnt = 0;
+    bool recording = true;                                                                    // :202 (the scan starts "recording")
+    for (uint64_t i = 0; i < t; ++i) {
+        if (var[i] >= th && !recording) { start = i; recording = true; }                      // :204-207
+        if (var[i] < th && recording) {                                                       // :208-213
+            recording = false;
+            if (i - start > min_len) { if (cnt < capacity) { ranges[2 * cnt] = start; ranges[2 * cnt + 1] = i; } ++cnt; }
+        }
+    }
+    *n_ranges = cnt;
+    return APD_OK;
+}
 
 extern "C" int apd_encode(apd_context *ctx, const float *x, uint64_t t, uint32_t d_in, const float *w_encode,
                           const float *b_encode, uint32_t latent, int on_device, float *out)

@@ -1,6 +1,10 @@
-"""Host mirror of the forward half of src/neural.rs: AutoEncoder::{n_latent, predict}.
-Training (take_step) and bincode (de)serialisation are outside the accelerated path."""
+"""Host mirror of the forward half of src/neural.rs: AutoEncoder::{n_latent, predict, from_file, save_file}.
+Training (take_step) is outside the accelerated path.  from_file / save_file read and write the
+reference's `output/encoder/auto_encoder.bin` (bincode 1.x default configuration: little-endian, usize and Vec
+lengths as u64, f32 as 4 bytes; struct fields in declaration order -- neural.rs:13-19, numerics.rs:171-174), so the
+weights of a real reference run can be fed to apd_encode."""
 import ctypes as C
+import struct
 
 import numpy as np
 
@@ -25,6 +29,47 @@ class AutoEncoder:
         self.w_encode = w_encode if isinstance(w_encode, Mat) else Mat(w_encode, np.asarray(w_encode).shape[1])
         self.b_encode = b_encode if isinstance(b_encode, Mat) else Mat(b_encode, np.asarray(b_encode).size)
         self.w_decode, self.b_decode = w_decode, b_decode
+
+    @staticmethod
+    def from_bytes(buf):
+        """bincode::deserialize::<AutoEncoder> (neural.rs:30-36): w_encode, w_decode, b_encode, b_decode, each a
+        Mat { flat: Vec<f32>, cols: usize }."""
+        mats, pos = [], 0
+        for _ in range(4):
+            if pos + 8 > len(buf):
+                raise ValueError("truncated bincode AutoEncoder")
+            (n,) = struct.unpack_from("<Q", buf, pos)
+            pos += 8
+            if pos + 4 * n + 8 > len(buf):
+                raise ValueError("truncated bincode AutoEncoder")
+            flat = np.frombuffer(buf, dtype="<f4", count=n, offset=pos).astype(np.float32)
+            pos += 4 * n
+            (cols,) = struct.unpack_from("<Q", buf, pos)
+            pos += 8
+            if cols == 0 or n % cols:
+                raise ValueError("Mat with %d values and %d columns" % (n, cols))
+            mats.append(Mat(flat, cols))
+        if pos != len(buf):
+            raise ValueError("trailing bytes after bincode AutoEncoder")
+        return AutoEncoder(mats[0], mats[2], mats[1], mats[3])
+
+    @staticmethod
+    def from_file(file):                      # neural.rs:30-36
+        with open(file, "rb") as fp:
+            return AutoEncoder.from_bytes(fp.read())
+
+    def to_bytes(self):                       # bincode::serialize (neural.rs:39-44)
+        out = b""
+        for m in (self.w_encode, self.w_decode, self.b_encode, self.b_decode):
+            if m is None:
+                raise ValueError("decoder half missing: cannot serialise")
+            m = m if isinstance(m, Mat) else Mat(m, np.asarray(m).shape[-1])
+            out += struct.pack("<Q", m.flat.size) + m.flat.astype("<f4").tobytes() + struct.pack("<Q", m.cols)
+        return out
+
+    def save_file(self, file):                # neural.rs:39-44
+        with open(file, "wb") as fp:
+            fp.write(self.to_bytes())
 
     def n_latent(self):                       # neural.rs:22-24
         return self.b_encode.cols

@@ -167,6 +167,12 @@ int apd_cepstrum(apd_context *ctx, const int16_t *samples, uint64_t n_samples, u
                  uint32_t fft_step, uint32_t filter_size, int on_device, float *out, uint64_t *n_frames,
                  uint32_t *n_bins);
 
+/* NDSequence::interesting_ranges (src/spectrogram.rs:174-216), the "VAT" pre-segmentation that precedes the path:
+ * per-frame std, mean of the `moving_average` previous values, percentile threshold, runs longer than min_len.
+ * frames: [t][n_bins] (device if on_device).  ranges: (start, stop) frame pairs, host; *n_ranges may exceed capacity. */
+int apd_interesting_ranges(apd_context *ctx, const float *frames, uint64_t t, uint32_t n_bins, uint32_t moving_average,
+                           float perc, uint64_t min_len, int on_device, uint64_t *ranges, uint64_t capacity,
+                           uint64_t *n_ranges);
 /* The same for n_seq recordings stored back to back (sample_offsets: n_seq+1): one launch for the whole corpus.
  * frame_offsets (n_seq+1, host, always written) and out ([frame_offsets[n_seq]][*n_bins], packed) are exactly the
  * `offsets` / `frames` arguments of apd_batch_create, so with on_device != 0 features go from audio to the

@@ -553,3 +553,40 @@ uint64_t orc_cepstrum(const int16_t *samples, uint64_t n_samples, uint32_t fft_s
     free(hamming); free(triag); free(win); free(mag); free(conv); free(ceps); free(ctab); free(stab);
     return T;
 }
+
+/* ---------------------------------------------------------------------- VAT */
+
+/* spectrogram.rs:174-187 */
+void orc_variance(const float *frames, uint64_t t, uint32_t n_bins, uint32_t k, float *out)
+{
+    float *deltas = (float *)malloc(sizeof(float) * (t ? t : 1));
+    for (uint64_t i = 0; i < t; i++) {
+        const float *v = frames + i * (uint64_t)n_bins;
+        float m = orc_mean(v, n_bins);
+        deltas[i] = orc_std(v, n_bins, m);
+    }
+    for (uint64_t i = 0; i < t; i++) out[i] = (i >= k) ? orc_mean(deltas + (i - k), k) : 0.0f;
+    free(deltas);
+}
+
+/* spectrogram.rs:192-216 */
+int orc_interesting_ranges(const float *frames, uint64_t t, uint32_t n_bins, uint32_t moving_average, float perc,
+                           uint64_t min_len, uint64_t *ranges, uint64_t capacity, uint64_t *n_ranges)
+{
+    float *var = (float *)malloc(sizeof(float) * (t ? t : 1));
+    orc_variance(frames, t, n_bins, moving_average, var);
+    float th;
+    if (orc_percentile(var, t, perc, &th) != 0) { free(var); return -1; }     /* :198 */
+    uint64_t start = 0, cnt = 0;
+    int recording = 1;                                                           /* :202 */
+    for (uint64_t i = 0; i < t; i++) {
+        if (var[i] >= th && !recording) { start = i; recording = 1; }           /* :204-207 */
+        if (var[i] < th && recording) {                                          /* :208-213 */
+            recording = 0;
+            if (i - start > min_len) { if (cnt < capacity) { ranges[2 * cnt] = start; ranges[2 * cnt + 1] = i; } cnt++; }
+        }
+    }
+    *n_ranges = cnt;
+    free(var);
+    return 0;
+}

@@ -104,6 +104,17 @@ void orc_encode(const float *x, uint64_t t, uint32_t d_in, const float *w, const
 uint64_t orc_cepstrum(const int16_t *samples, uint64_t n_samples, uint32_t fft_size,
                       uint32_t fft_step, uint32_t filter_size, float *out, uint32_t *n_bins);
 
+/* spectrogram.rs:174-187 -- NDSequence::variance(k): per-frame population std, then the mean of the k PREVIOUS
+ * values (0.0 for i < k).  frames: [t][n_bins]; out: [t]. */
+void orc_variance(const float *frames, uint64_t t, uint32_t n_bins, uint32_t k, float *out);
+
+/* spectrogram.rs:192-216 -- NDSequence::interesting_ranges: threshold = percentile(variance(k), perc); a range opens
+ * at the first value >= threshold (the scan STARTS in the recording state at 0), closes at the first value below it,
+ * and is kept if stop - start > min_len; a range still open at the end is dropped.  ranges: (start, stop) pairs.
+ * Returns 0, or -1 where the reference panics (percentile index out of range). */
+int orc_interesting_ranges(const float *frames, uint64_t t, uint32_t n_bins, uint32_t moving_average, float perc,
+                           uint64_t min_len, uint64_t *ranges, uint64_t capacity, uint64_t *n_ranges);
+
 #ifdef __cplusplus
 }
 #endif

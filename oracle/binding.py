@@ -70,6 +70,10 @@ def lib():
     L.orc_cepstrum.restype = C.c_uint64
     L.orc_cepstrum.argtypes = [C.POINTER(C.c_int16), C.c_uint64, C.c_uint32, C.c_uint32,
                                C.c_uint32, f32p, u32p]
+    L.orc_variance.restype = None
+    L.orc_variance.argtypes = [f32p, C.c_uint64, C.c_uint32, C.c_uint32, f32p]
+    L.orc_interesting_ranges.restype = C.c_int
+    L.orc_interesting_ranges.argtypes = [f32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64, u64p, C.c_uint64, u64p]
     _lib = L
     return L
 
@@ -188,3 +192,22 @@ def cepstrum(samples, fft_size, fft_step, filter_size):
         lib().orc_cepstrum(_p(s, C.c_int16), s.size, fft_size, fft_step, filter_size,
                            _p(out, C.c_float), C.byref(nb))
     return out
+
+
+def variance(frames, k):
+    """NDSequence::variance (spectrogram.rs:174-187)."""
+    f = _f32(frames)
+    out = np.empty(f.shape[0], dtype=np.float32)
+    lib().orc_variance(_p(f, C.c_float), f.shape[0], f.shape[1], int(k), _p(out, C.c_float))
+    return out
+
+
+def interesting_ranges(frames, moving_average, perc, min_len):
+    """NDSequence::interesting_ranges (spectrogram.rs:192-216) -> [(start, stop), ...]."""
+    f = _f32(frames)
+    ranges = np.zeros(2 * max(f.shape[0], 1), dtype=np.uint64)
+    n = C.c_uint64(0)
+    if lib().orc_interesting_ranges(_p(f, C.c_float), f.shape[0], f.shape[1], int(moving_average), float(perc), int(min_len),
+                                    _p(ranges, C.c_uint64), f.shape[0], C.byref(n)) != 0:
+        raise IndexError("percentile index out of range (the reference panics here)")
+    return [(int(ranges[2 * i]), int(ranges[2 * i + 1])) for i in range(n.value)]

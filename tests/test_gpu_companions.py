@@ -135,3 +135,21 @@ def test_audio_to_clusters_on_device(ctx, oracle, apd):
                                rtol=0, atol=3e-4)
     assert got[2, 7] == 0.0 and got[7, 2] == 0.0
     np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-5)
+
+
+def test_interesting_ranges_vat(ctx, oracle, apd):
+    """NDSequence::interesting_ranges (spectrogram.rs:174-216): GPU variance + percentile select vs the oracle."""
+    from audio_pattern_discovery_amd.alignments import NDSequence
+    rng = np.random.default_rng(4)
+    f = rng.standard_normal((3000, 13)).astype(np.float32)
+    for a, b, g in [(100, 400, 5.0), (900, 1000, 7.0), (1500, 1510, 9.0), (2000, 2600, 3.0)]:
+        f[a:b] *= g
+    seq = NDSequence(f)
+    for moving, perc, min_len in [(15, 0.5, 150), (15, 0.95, 5), (1, 0.3, 0), (40, 0.8, 60)]:
+        got = [(s.start, s.stop) for s in seq.interesting_ranges(moving, perc, min_len, ctx)]
+        assert got == oracle.interesting_ranges(f, moving, perc, min_len)
+    sl = seq.interesting_ranges(15, 0.5, 150, ctx)[0]
+    assert sl.extract().len() == sl.len() and sl.extract().n_bins == 13
+    with pytest.raises(apd.ApdError) as e:
+        seq.interesting_ranges(15, 1.0, 10, ctx)                          # percentile index == len: the reference panics
+    assert e.value.status == apd.APD_ERR_INDEX

@@ -117,3 +117,30 @@ def test_cluster_sets_host_matches_oracle(oracle):
     mine = [ClusteringOperation(o["merge_i"], o["merge_j"], o["into"], o["distance"], Merge[o["operation"]]) for o in ops]
     assert AgglomerativeClustering.cluster_sets(mine, set(roots), 12) == oracle.cluster_sets(ops, roots, 12)
     assert AgglomerativeClustering.cluster_sets([], {0, 1, 2}, 3) == []      # singletons omitted (clustering.rs:71)
+
+
+def test_autoencoder_bincode_layout(tmp_path):
+    """`auto_encoder.bin` as bincode 1.x writes it (neural.rs:13-19,30-44): four Mat{flat: Vec<f32>, cols: usize}."""
+    import struct
+    from audio_pattern_discovery_amd.neural import AutoEncoder, Mat
+
+    def mat(rows, cols, base):
+        vals = [base + 0.5 * i for i in range(rows * cols)]
+        return struct.pack("<Q", len(vals)) + struct.pack("<%df" % len(vals), *vals) + struct.pack("<Q", cols), vals
+
+    blob, want = b"", []
+    for rows, cols, base in ((3, 2, 1.0), (2, 3, -4.0), (1, 2, 10.0), (1, 3, 20.0)):   # w_encode, w_decode, b_encode, b_decode
+        b, v = mat(rows, cols, base)
+        blob += b
+        want.append((v, cols))
+    nn = AutoEncoder.from_bytes(blob)
+    assert nn.w_encode.flat.tolist() == want[0][0] and nn.w_encode.cols == 2 and nn.w_encode.rows() == 3
+    assert nn.w_decode.flat.tolist() == want[1][0] and nn.w_decode.cols == 3
+    assert nn.b_encode.flat.tolist() == want[2][0] and nn.n_latent() == 2
+    assert nn.b_decode.flat.tolist() == want[3][0]
+    assert nn.to_bytes() == blob                                       # byte-exact round trip
+    nn.save_file(str(tmp_path / "auto_encoder.bin"))
+    assert AutoEncoder.from_file(str(tmp_path / "auto_encoder.bin")).to_bytes() == blob
+    for bad in (blob[:-1], blob + b"\\0", blob[:5]):
+        with pytest.raises(ValueError):
+            AutoEncoder.from_bytes(bad)
