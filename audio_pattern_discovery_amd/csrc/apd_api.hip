@@ -2,6 +2,7 @@
 // host-side plumbing around the alignment kernels.  No torch, no CPU fallback.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <new>
@@ -253,7 +254,7 @@ extern "C" int apd_batch_destroy(apd_batch *b)
 {
     if (!b) return APD_ERR_INVALID_ARG;
     if (b->ctx) { hipSetDevice(b->ctx->device); hipStreamSynchronize(b->ctx->stream); }
-    for (auto &kv : b->tile_cache) hipFree(kv.second.first);
+    for (auto &kv : b->tile_cache) hipFree(kv.second.d_tiles);
     if (b->d_frames) hipFree(b->d_frames);
     if (b->d_seq_off) hipFree(b->d_seq_off);
     delete b;
@@ -335,33 +336,62 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
     int rc = check_lengths(batch);
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    auto &entry = batch->tile_cache[((uint64_t)rank << 32) | world];
-    if (!entry.first) {
+    // Tiles are grouped by the kernel geometry their widest pair needs (w is bounded per tile from the lengths of its
+    // 32 sequences), one launch per group: a few long or unequal sequences do not force every pair onto a wide kernel.
+    const bool pens_ok = (band.ins > 0.0f) && (band.del > 0.0f) && (band.mat > 0.0f) && (band.ins < INFINITY) &&
+                         (band.del < INFINITY) && (band.mat < INFINITY);   // the systolic kernel needs pen * INF = INF
+    const bool fast_ok = pens_ok && batch->frames_bytes != 0;
+    char keybuf[160];
+    uint32_t pct_bits;
+    std::memcpy(&pct_bits, &band.pct, sizeof(pct_bits));
+    std::snprintf(keybuf, sizeof(keybuf), "%u/%u/%08x/%u/%d/%d/%d", rank, world, pct_bits, band.explicit_band, band.use_explicit,
+                  ctx->variant, (int)fast_ok);
+    apd_batch::TilePlan &plan = batch->tile_cache[keybuf];
+    if (!plan.d_tiles) {
         std::vector<uint2> tiles;
         rank_tile_list(batch->n_seq, rank, world, tiles);
-        entry.second = (uint32_t)tiles.size();
-        HIP_TRY(ctx, hipMalloc((void **)&entry.first, std::max<size_t>(tiles.size(), 1) * sizeof(uint2)));
-        if (!tiles.empty()) {
-            HIP_TRY(ctx, hipMemcpyAsync(entry.first, tiles.data(), tiles.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+        // per tile-row (16 sequences) min / max length
+        const uint32_t side = tiles_side(batch->n_seq);
+        std::vector<uint32_t> lo(side, 0xFFFFFFFFu), hi(side, 0);
+        for (uint32_t s = 0; s < batch->n_seq; ++s) {
+            const uint32_t len = (uint32_t)(batch->offsets[s + 1] - batch->offsets[s]);
+            lo[s / kTile] = std::min(lo[s / kTile], len);
+            hi[s / kTile] = std::max(hi[s / kTile], len);
+        }
+        std::map<int, std::vector<uint4>> groups;
+        std::map<int, uint32_t> wmax;
+        for (uint32_t t = 0; t < tiles.size(); ++t) {
+            const uint32_t mx = std::max(hi[tiles[t].x], hi[tiles[t].y]), mn = std::min(lo[tiles[t].x], lo[tiles[t].y]);
+            const uint32_t band_ub = band.use_explicit ? band.explicit_band : host_band_from_pct(band.pct, mx);
+            const uint32_t w = std::max(std::min(band_ub, mx), mx - mn) + 2;   // >= w of every pair of the tile
+            const int key = fast_ok ? pick_geometry_key(2 * w + 1, batch->dim, ctx->variant) : 0;
+            groups[key].push_back(make_uint4(tiles[t].x, tiles[t].y, t, 0));
+            wmax[key] = std::max(wmax[key], w);
+        }
+        std::vector<uint4> flat;
+        for (auto &g : groups) {
+            plan.classes.push_back(apd_batch::TileClass{g.first, (uint32_t)flat.size(), (uint32_t)g.second.size(), wmax[g.first]});
+            flat.insert(flat.end(), g.second.begin(), g.second.end());
+        }
+        HIP_TRY(ctx, hipMalloc((void **)&plan.d_tiles, std::max<size_t>(flat.size(), 1) * sizeof(uint4)));
+        if (!flat.empty()) {
+            HIP_TRY(ctx, hipMemcpyAsync(plan.d_tiles, flat.data(), flat.size() * sizeof(uint4), hipMemcpyHostToDevice, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         }
     }
     AlignLaunch L{};
-    L.d_frames = batch->d_frames; L.frames_bytes = batch->frames_bytes; L.d_seq_off = batch->d_seq_off; L.d_tiles = entry.first; L.n_tiles = entry.second;
+    L.d_frames = batch->d_frames; L.frames_bytes = batch->frames_bytes; L.d_seq_off = batch->d_seq_off;
     L.n_seq = batch->n_seq; L.dim = batch->dim; L.dpad = batch->dpad; L.band = band; L.d_slab = d_slab;
     L.variant = ctx->variant;
     L.hybrid = ctx->distance_mode; L.tau = ctx->tau;
-    // upper bound of w over all pairs: the band is monotone in max(n,m), the gap is at most max_len - min_len
-    {
-        const uint32_t band_ub = band.use_explicit ? band.explicit_band : host_band_from_pct(band.pct, batch->max_len);
-        const uint32_t bclamp = std::min(band_ub, batch->max_len);
-        L.w_max = std::max(bclamp, batch->max_len - batch->min_len) + 2;
-    }
     if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    int status = APD_OK;
-    hipError_t e = launch_align(L, ctx->stream, ctx->last_error, &status);
-    if (e != hipSuccess) { ctx->last_error = std::string("launch_align: ") + hipGetErrorString(e); return APD_ERR_HIP; }
-    if (status != APD_OK) return status;
+    for (const apd_batch::TileClass &tc : plan.classes) {
+        L.d_tiles = plan.d_tiles + tc.first; L.n_tiles = tc.count; L.w_max = tc.w_max;
+        int status = APD_OK;
+        hipError_t e = launch_align(L, tc.geom_key, ctx->stream, ctx->last_error, &status);
+        if (e != hipSuccess) { ctx->last_error = std::string("launch_align: ") + hipGetErrorString(e); return APD_ERR_HIP; }
+        if (status != APD_OK) return status;
+    }
     if (ctx->timing) { HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream)); ctx->timed = true; }
     return APD_OK;
 }

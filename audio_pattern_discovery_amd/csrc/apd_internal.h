@@ -30,19 +30,21 @@ struct AlignLaunch {
     const float *d_frames;       // resident layout, see dtw_generic.hip: [frames | sentinel H | sentinel E] per sequence, dpad floats per frame
     uint32_t frames_bytes;       // size of d_frames in bytes (0 if >= 4 GiB: buffer addressing unavailable)
     const uint32_t *d_seq_off;   // [n_seq+1] padded frame offsets (sequence s owns seq_off[s+1]-seq_off[s]-2 real frames)
-    const uint2 *d_tiles;        // [n_tiles] (tile_a, tile_b), tile_a <= tile_b
+    const uint4 *d_tiles;        // [n_tiles] (tile_a, tile_b, index of the tile in the slab, unused), tile_a <= tile_b
     uint32_t n_tiles;
     uint32_t n_seq;
     uint32_t dim, dpad;
     BandSpec band;
-    float *d_slab;               // [n_tiles][2][kTile][kTile]
+    float *d_slab;               // [tiles of the rank][2][kTile][kTile]
     uint32_t w_max;              // upper bound of w over the pairs of this launch
     int variant;                 // 0 auto
     int hybrid;                  // 1: norm-expansion distances with exact recomputation below tau (see dtw_systolic.h)
     float tau;
 };
 
-hipError_t launch_align(const AlignLaunch &L, hipStream_t stream, std::string &err, int *status);
+// geom_key = G * 100 + C of the systolic kernel, or 0 for the generic kernel (see pick_geometry_key)
+hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, std::string &err, int *status);
+int pick_geometry_key(uint32_t need, uint32_t dim, int variant);
 hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_off, uint32_t n_seq, uint64_t n_frames_padded,
                       uint32_t dim, uint32_t dpad, hipStream_t stream);
 hipError_t launch_unpack(const float *d_gathered, float *d_out, uint32_t n_seq, uint32_t world,
@@ -97,6 +99,8 @@ struct apd_batch {
     uint32_t *d_seq_off = nullptr;
     std::vector<uint64_t> offsets;    // host copy
     uint32_t min_len = 0, max_len = 0;
-    // device-resident tile lists, keyed (rank << 32 | world)
-    mutable std::map<uint64_t, std::pair<uint2 *, uint32_t>> tile_cache;
+    // device-resident tile lists, grouped by the kernel geometry each tile needs
+    struct TileClass { int geom_key; uint32_t first, count, w_max; };
+    struct TilePlan { uint4 *d_tiles = nullptr; std::vector<TileClass> classes; };
+    mutable std::map<std::string, TilePlan> tile_cache;   // keyed by rank/world/band/variant
 };

@@ -85,6 +85,7 @@ struct PairInfo {
     const float *A, *B;
     int n, m, w;
     int slot_a, slot_b;
+    uint32_t slab_tile;     // position of the tile in the rank's slab
     bool valid;
 };
 
@@ -94,9 +95,11 @@ __device__ __forceinline__ PairInfo decode_pair(const AlignLaunch &L, uint32_t t
     p.slot_a = slot / kTile;
     p.slot_b = slot % kTile;
     p.valid = false;
+    p.slab_tile = 0;
     p.A = p.B = L.d_frames; p.n = p.m = 2; p.w = 2;
     if (tile >= L.n_tiles) return p;
-    const uint2 t = L.d_tiles[tile];
+    const uint4 t = L.d_tiles[tile];
+    p.slab_tile = t.z;
     const uint32_t a = t.x * kTile + p.slot_a, b = t.y * kTile + p.slot_b;
     if (!((a < b) && (b < L.n_seq))) return p;
     p.valid = true;
@@ -109,9 +112,9 @@ __device__ __forceinline__ PairInfo decode_pair(const AlignLaunch &L, uint32_t t
     return p;
 }
 
-__device__ __forceinline__ void store_pair(const AlignLaunch &L, uint32_t tile, const PairInfo &p, float s1, float s2)
+__device__ __forceinline__ void store_pair(const AlignLaunch &L, uint32_t, const PairInfo &p, float s1, float s2)
 {
-    float *slab = L.d_slab + (uint64_t)tile * 2 * kSlotsPerTile;
+    float *slab = L.d_slab + (uint64_t)p.slab_tile * 2 * kSlotsPerTile;
     slab[p.slot_a * kTile + p.slot_b] = s1;                       // score(x=a, y=b)
     slab[kSlotsPerTile + p.slot_a * kTile + p.slot_b] = s2;       // score(x=b, y=a)
 }

@@ -193,9 +193,15 @@ hipError_t launch_unpack(const float *d_gathered, float *d_out, uint32_t n_seq, 
 // ------------------------------------------------------------------------------------------------
 struct Geometry { int g, c; };
 
-// Pick the (lanes per pair, offsets per lane) that wastes the fewest lanes for a band of `need` offsets.
-static Geometry pick_geometry(uint32_t need, uint32_t dim)
+// Pick the (lanes per pair, offsets per lane) that wastes the fewest lanes for a band of `need` offsets; 0 = generic.
+int pick_geometry_key(uint32_t need, uint32_t dim, int variant)
 {
+    if (variant == 1) return 0;                                        // forced generic kernel
+    if (!(dim == 8 || dim == 10 || dim == 13 || dim == 26)) return 0;  // instantiated frame dimensions
+    if (variant >= 100) {                                              // forced geometry (tuning)
+        const int g = variant / 100, c = variant % 100;
+        return ((uint32_t)(g * c) >= need) ? variant : 0;
+    }
     static const Geometry all[] = {{16, 2}, {16, 3}, {16, 5}, {16, 9}, {64, 3}, {64, 5}, {64, 9}};   // (8, 9) only on request
     Geometry best{0, 0};
     double best_util = 0.0;
@@ -204,32 +210,26 @@ static Geometry pick_geometry(uint32_t need, uint32_t dim)
         const double util = (double)need / (double)(q.g * q.c) - 0.004 * (9 - q.c);   // larger C: fewer exchanges per cell
         if (util > best_util) { best_util = util; best = q; }
     }
-    return best;
+    return best.g * 100 + best.c;
 }
 
-hipError_t launch_align(const AlignLaunch &L, hipStream_t stream, std::string &err, int *status)
+hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, std::string &err, int *status)
 {
     *status = APD_OK;
     if (L.n_tiles == 0) return hipSuccess;
     const BandSpec &b = L.band;
     const bool uniform = (b.ins == b.del) && (b.del == b.mat);
-    // the systolic kernel turns boundary cells into +INF through pen * INF: needs finite penalties > 0
-    const bool pens_ok = (b.ins > 0.0f) && (b.del > 0.0f) && (b.mat > 0.0f) && (b.ins < APD_INF) && (b.del < APD_INF) &&
-                         (b.mat < APD_INF);
     bool done = false;
     AlignLaunch LL = L;
     if (LL.dim < 10) LL.hybrid = 0;            // the norm expansion saves D - 4 vector ops per cell: not worth its branch below D = 10
-    if (L.variant != 1 && pens_ok && L.frames_bytes != 0) {
-        Geometry q = pick_geometry(2 * L.w_max + 1, L.dim);
-        if (L.variant >= 100) { q.g = L.variant / 100; q.c = L.variant % 100; if ((uint32_t)(q.g * q.c) < 2 * L.w_max + 1) q.g = 0; }
-        if (q.g != 0) {
-            switch (L.dim) {
-                case 8: done = launch_systolic<8>(LL, q.g, q.c, uniform, stream); break;   // L.hybrid picks the distance form
-                case 10: done = launch_systolic<10>(LL, q.g, q.c, uniform, stream); break;
-                case 13: done = launch_systolic<13>(LL, q.g, q.c, uniform, stream); break;
-                case 26: done = launch_systolic<26>(LL, q.g, q.c, uniform, stream); break;
-                default: break;
-            }
+    if (geom_key != 0) {
+        const int g = geom_key / 100, c = geom_key % 100;
+        switch (L.dim) {
+            case 8: done = launch_systolic<8>(LL, g, c, uniform, stream); break;
+            case 10: done = launch_systolic<10>(LL, g, c, uniform, stream); break;
+            case 13: done = launch_systolic<13>(LL, g, c, uniform, stream); break;
+            case 26: done = launch_systolic<26>(LL, g, c, uniform, stream); break;
+            default: break;
         }
     }
     if (!done) {

@@ -253,3 +253,17 @@ def test_near_duplicates_hybrid_distance_accuracy(ctx, oracle, scale):
     assert_parity(got, want)
     if scale == 0.0:
         assert got[0, 6] == 0.0 and got[6, 0] == 0.0 and got[12, 14] == 0.0
+
+
+@pytest.mark.parametrize("pct", [0.0625, 1.0])
+def test_mixed_lengths_use_several_kernel_geometries(ctx, oracle, pct):
+    """Lengths from 3 to ~700 in one batch: tiles are grouped by the band their widest pair needs, so this run goes
+    through several systolic geometries AND the generic kernel in one align_all; every entry must still match."""
+    rng = np.random.default_rng(23)
+    lens = np.concatenate([rng.integers(3, 40, 20), rng.integers(60, 90, 20), rng.integers(250, 300, 12), rng.integers(600, 700, 6)])
+    seqs = [np.cumsum(rng.standard_normal((int(n), 13)), axis=0).astype(np.float32) * 0.3 for n in lens]
+    frames = np.concatenate(seqs)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    want = oracle.align_all(frames, offsets, pct, workers=8)
+    got = gpu_align_all(ctx, frames, offsets, 13, pct)
+    assert_parity(got, want)
