@@ -341,6 +341,7 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
     const bool pens_ok = (band.ins > 0.0f) && (band.del > 0.0f) && (band.mat > 0.0f) && (band.ins < INFINITY) &&
                          (band.del < INFINITY) && (band.mat < INFINITY);   // the systolic kernel needs pen * INF = INF
     const bool fast_ok = pens_ok && batch->frames_bytes != 0;
+    const bool uniform_pen = (band.ins == band.del) && (band.del == band.mat);
     char keybuf[160];
     uint32_t pct_bits;
     std::memcpy(&pct_bits, &band.pct, sizeof(pct_bits));
@@ -364,7 +365,7 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
             const uint32_t mx = std::max(hi[tiles[t].x], hi[tiles[t].y]), mn = std::min(lo[tiles[t].x], lo[tiles[t].y]);
             const uint32_t band_ub = band.use_explicit ? band.explicit_band : host_band_from_pct(band.pct, mx);
             const uint32_t w = std::max(std::min(band_ub, mx), mx - mn) + 2;   // >= w of every pair of the tile
-            const int key = fast_ok ? pick_geometry_key(2 * w + 1, batch->dim, ctx->variant) : 0;
+            const int key = fast_ok ? pick_geometry_key(2 * w + 1, batch->dim, ctx->variant, uniform_pen) : 0;
             groups[key].push_back(make_uint4(tiles[t].x, tiles[t].y, t, 0));
             wmax[key] = std::max(wmax[key], w);
         }

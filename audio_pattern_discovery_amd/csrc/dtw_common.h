@@ -128,4 +128,12 @@ extern template bool launch_systolic<10>(const AlignLaunch &, int, int, bool, hi
 extern template bool launch_systolic<13>(const AlignLaunch &, int, int, bool, hipStream_t);
 extern template bool launch_systolic<26>(const AlignLaunch &, int, int, bool, hipStream_t);
 
+// Wide-band kernel (dtw_wide.h): NW waves per pair; returns false when (NW, C) is not instantiated.
+template <int D>
+bool launch_wide(const AlignLaunch &L, int nw, int c, hipStream_t stream, hipError_t *err);
+extern template bool launch_wide<8>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
+extern template bool launch_wide<10>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
+extern template bool launch_wide<13>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
+extern template bool launch_wide<26>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
+
 }  // namespace apd

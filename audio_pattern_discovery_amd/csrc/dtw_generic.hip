@@ -194,10 +194,14 @@ hipError_t launch_unpack(const float *d_gathered, float *d_out, uint32_t n_seq, 
 struct Geometry { int g, c; };
 
 // Pick the (lanes per pair, offsets per lane) that wastes the fewest lanes for a band of `need` offsets; 0 = generic.
-int pick_geometry_key(uint32_t need, uint32_t dim, int variant)
+int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen)
 {
     if (variant == 1) return 0;                                        // forced generic kernel
     if (!(dim == 8 || dim == 10 || dim == 13 || dim == 26)) return 0;  // instantiated frame dimensions
+    if (variant >= 10000) {                                            // forced wide geometry (tuning)
+        const int nw = (variant - 10000) / 100, c = variant % 100;
+        return (uniform_pen && (uint32_t)(64 * nw * c) >= need) ? variant : 0;
+    }
     if (variant >= 100) {                                              // forced geometry (tuning)
         const int g = variant / 100, c = variant % 100;
         return ((uint32_t)(g * c) >= need) ? variant : 0;
@@ -210,7 +214,14 @@ int pick_geometry_key(uint32_t need, uint32_t dim, int variant)
         const double util = (double)need / (double)(q.g * q.c) - 0.004 * (9 - q.c);   // larger C: fewer exchanges per cell
         if (util > best_util) { best_util = util; best = q; }
     }
-    return best.g * 100 + best.c;
+    if (best.g != 0) return best.g * 100 + best.c;
+    // beyond one wavefront: NW waves per pair (dtw_wide.h), uniform penalties only
+    if (uniform_pen) {
+        static const Geometry wide[] = {{4, 5}, {4, 9}, {8, 5}, {8, 9}};          // (NW, C), ascending capacity
+        for (const Geometry &q : wide)
+            if ((uint32_t)(64 * q.g * q.c) >= need && !(q.c == 9 && dim > 16)) return 10000 + q.g * 100 + q.c;
+    }
+    return 0;
 }
 
 hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, std::string &err, int *status)
@@ -222,7 +233,18 @@ hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, 
     bool done = false;
     AlignLaunch LL = L;
     if (LL.dim < 10) LL.hybrid = 0;            // the norm expansion saves D - 4 vector ops per cell: not worth its branch below D = 10
-    if (geom_key != 0) {
+    if (geom_key >= 10000) {
+        const int nw = (geom_key - 10000) / 100, c = geom_key % 100;
+        hipError_t we = hipSuccess;
+        switch (L.dim) {
+            case 8: done = launch_wide<8>(LL, nw, c, stream, &we); break;
+            case 10: done = launch_wide<10>(LL, nw, c, stream, &we); break;
+            case 13: done = launch_wide<13>(LL, nw, c, stream, &we); break;
+            case 26: done = launch_wide<26>(LL, nw, c, stream, &we); break;
+            default: break;
+        }
+        if (done && we != hipSuccess) return we;
+    } else if (geom_key != 0) {
         const int g = geom_key / 100, c = geom_key % 100;
         switch (L.dim) {
             case 8: done = launch_systolic<8>(LL, g, c, uniform, stream); break;

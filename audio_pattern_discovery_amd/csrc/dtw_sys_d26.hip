@@ -1,5 +1,6 @@
-// Instantiates the systolic fused-pair DTW kernel for frame dimension 26 (one unit per D so they build in parallel).
-#include "dtw_systolic.h"
+// Instantiates the systolic and the wide fused-pair DTW kernels for frame dimension 26 (one unit per D: parallel builds).
+#include "dtw_wide.h"
 namespace apd {
 template bool launch_systolic<26>(const AlignLaunch &, int, int, bool, hipStream_t);
+template bool launch_wide<26>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
 }

@@ -267,3 +267,28 @@ def test_mixed_lengths_use_several_kernel_geometries(ctx, oracle, pct):
     want = oracle.align_all(frames, offsets, pct, workers=8)
     got = gpu_align_all(ctx, frames, offsets, 13, pct)
     assert_parity(got, want)
+
+
+@pytest.mark.parametrize("variant", [10405, 10409, 10805, 10809])
+@pytest.mark.parametrize("distance", ["hybrid", "exact"])
+def test_wide_kernel_geometries(ctx, oracle, variant, distance):
+    """dtw_fused_wide (NW waves per pair, LDS mailboxes at the wave seams) in every instantiated geometry, full DTW and
+    a binding band, on lengths that put the result cell, the D[0][0] injection and the band edges in different waves."""
+    rng = np.random.default_rng(variant)
+    lens = [2, 3, 70, 130, 260, 333, 520, 611]
+    seqs = [np.cumsum(rng.standard_normal((n, 13)), axis=0).astype(np.float32) * 0.4 for n in lens]
+    seqs.append(seqs[5].copy())                                          # exact duplicate: 0.0
+    frames = np.concatenate(seqs)
+    offsets = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint64)
+    from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
+    from audio_pattern_discovery_amd.discovery import Discovery
+    for pct in (1.0, 0.3):
+        want = oracle.align_all(frames, offsets, pct, workers=8)
+        ctx.set_distance_mode(distance)
+        ctx.set_variant(variant)
+        w = AlignmentWorkers.new([NDSequence(s) for s in seqs], ctx)
+        got = w.align_all(Discovery(warping_band_percentage=pct)).reshape(len(seqs), len(seqs)).copy()
+        ctx.set_variant(0)
+        ctx.set_distance_mode("hybrid")
+        assert_parity(got, want)
+        assert got[5, 8] == 0.0 and got[8, 5] == 0.0
