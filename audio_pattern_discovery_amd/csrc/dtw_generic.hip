@@ -217,7 +217,7 @@ int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen
     if (best.g != 0) return best.g * 100 + best.c;
     // beyond one wavefront: NW waves per pair (dtw_wide.h), uniform penalties only
     if (uniform_pen) {
-        static const Geometry wide[] = {{4, 5}, {4, 9}, {8, 5}, {8, 9}};          // (NW, C), ascending capacity
+        static const Geometry wide[] = {{2, 5}, {2, 9}, {4, 5}, {4, 9}, {8, 5}, {8, 9}};   // (NW, C), ascending capacity
         for (const Geometry &q : wide)
             if ((uint32_t)(64 * q.g * q.c) >= need && !(q.c == 9 && dim > 16)) return 10000 + q.g * 100 + q.c;
     }

@@ -2,7 +2,7 @@
 //
 // dtw_fused_systolic keeps a pair inside one wavefront, so it tops out at 64 lanes x 9 offsets = 576 band offsets --
 // full DTW (the reference's shipped warping_band_percentage = 1.0) on anything longer than ~285 frames would fall to
-// the generic kernel, ~40x slower per cell.  Here ONE workgroup of NW waves (256 or 512 lanes) sweeps one unordered
+// the generic kernel, ~40x slower per cell.  Here ONE workgroup of NW waves (128, 256 or 512 lanes) sweeps one unordered
 // pair: lane gl = threadIdx.x owns offsets u = C*gl + c exactly as before, neighbours inside a wave talk through DPP,
 // and the NW-1 wave seams go through tiny LDS mailboxes:
 //   left[wv+1]  last DP cells of lane 63 of wave wv      (read by lane 0 of wave wv+1 at the next macro-step)
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(64 * NW) void dtw_fused_wide(const AlignLaunch L)
     constexpr int DP = (DN + 3) & ~3;
     constexpr int S = C + 1;
     constexpr int U = (S % 2 == 0) ? S : 2 * S;
-    constexpr int R = (G == 256) ? 512 : 1024;                   // row ring: R > 2U + G - 2
+    constexpr int R = (G <= 256) ? 512 : 1024;                   // row ring: R > 2U + G - 2
     constexpr int LPF = DP / 4, FPF = 64 / LPF, NFILL = (U + FPF - 1) / FPF;
     constexpr uint32_t FB = DP * 4u;
     extern __shared__ float lds[];
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64 * NW) void dtw_fused_wide(const AlignLaunch L)
 template <int D, int C, int NW>
 static hipError_t launch_wide_cn(const AlignLaunch &L, hipStream_t stream)
 {
-    constexpr int G = 64 * NW, DP = (D + 1 + 3) & ~3, R = (G == 256) ? 512 : 1024;
+    constexpr int G = 64 * NW, DP = (D + 1 + 3) & ~3, R = (G <= 256) ? 512 : 1024;
     const size_t lds_bytes = ((size_t)R * DP + (NW + 1) * DP + 4 * (NW + 1)) * sizeof(float);
     const dim3 grid(L.n_tiles * kSlotsPerTile), block(G);
     const bool hybrid = L.hybrid && D >= 10;
@@ -242,7 +242,7 @@ template <int D>
 bool launch_wide(const AlignLaunch &L, int nw, int c, hipStream_t stream, hipError_t *err)
 {
 #define APD_WCASE(NN, CC) if constexpr (CC < 9 || D <= 16) { if (nw == NN && c == CC) { *err = launch_wide_cn<D, CC, NN>(L, stream); return true; } }
-    APD_WCASE(4, 5) APD_WCASE(4, 9) APD_WCASE(8, 5) APD_WCASE(8, 9)
+    APD_WCASE(2, 5) APD_WCASE(2, 9) APD_WCASE(4, 5) APD_WCASE(4, 9) APD_WCASE(8, 5) APD_WCASE(8, 9)
 #undef APD_WCASE
     return false;
 }
