@@ -365,7 +365,15 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
             const uint32_t mx = std::max(hi[tiles[t].x], hi[tiles[t].y]), mn = std::min(lo[tiles[t].x], lo[tiles[t].y]);
             const uint32_t band_ub = band.use_explicit ? band.explicit_band : host_band_from_pct(band.pct, mx);
             const uint32_t w = std::max(std::min(band_ub, mx), mx - mn) + 2;   // >= w of every pair of the tile
-            const int key = fast_ok ? pick_geometry_key(2 * w + 1, batch->dim, ctx->variant, uniform_pen) : 0;
+            int key = fast_ok ? pick_geometry_key(2 * w + 1, batch->dim, ctx->variant, uniform_pen) : 0;
+            // the band binds nowhere in this tile (band >= longest - 3 for its longest sequence, hence for all) and the penalties
+            // are equal: both ordered scores are one number, swept over column strips (dtw_full.h).  Not for very short columns,
+            // where four pairs per wavefront in band form keep more lanes busy.
+            const uint32_t cols = std::min(hi[tiles[t].x], hi[tiles[t].y]);
+            if (fast_ok && uniform_pen && mx >= 3 && std::min(band_ub, mx) >= mx - 3 && (cols >= 49 || ctx->variant >= 20000)) {
+                const int fk = pick_full_key(cols > 0 ? cols - 1 : 0, batch->dim, ctx->variant);
+                if (fk != 0) key = fk;
+            }
             groups[key].push_back(make_uint4(tiles[t].x, tiles[t].y, t, 0));
             wmax[key] = std::max(wmax[key], w);
         }

@@ -44,7 +44,9 @@ struct AlignLaunch {
 
 // geom_key = G * 100 + C of the systolic kernel, or 0 for the generic kernel (see pick_geometry_key)
 hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, std::string &err, int *status);
-int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen);   // >= 10000: wide kernel, 10000 + NW * 100 + C
+int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen);
+// >= 20000: full-matrix kernel, 20000 + NW * 100 + CW, for `cols` columns (0 if none fits)
+int pick_full_key(uint32_t cols, uint32_t dim, int variant);   // >= 10000: wide kernel, 10000 + NW * 100 + C
 hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_off, uint32_t n_seq, uint64_t n_frames_padded,
                       uint32_t dim, uint32_t dpad, hipStream_t stream);
 hipError_t launch_unpack(const float *d_gathered, float *d_out, uint32_t n_seq, uint32_t world,

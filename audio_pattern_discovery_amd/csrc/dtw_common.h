@@ -136,4 +136,12 @@ extern template bool launch_wide<10>(const AlignLaunch &, int, int, hipStream_t,
 extern template bool launch_wide<13>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
 extern template bool launch_wide<26>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
 
+// Full-matrix kernel (dtw_full.h): column strips, one DP for both ordered pairs.
+template <int D>
+bool launch_full(const AlignLaunch &L, int nw, int cw, hipStream_t stream, hipError_t *err);
+extern template bool launch_full<8>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
+extern template bool launch_full<10>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
+extern template bool launch_full<13>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
+extern template bool launch_full<26>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
+
 }  // namespace apd

@@ -224,6 +224,20 @@ int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen
     return 0;
 }
 
+int pick_full_key(uint32_t cols, uint32_t dim, int variant)
+{
+    if (variant != 0 && variant < 20000) return 0;                     // another kernel was requested
+    if (!(dim == 8 || dim == 10 || dim == 13 || dim == 26)) return 0;
+    if (variant >= 20000) {
+        const int nw = (variant - 20000) / 100, cw = variant % 100;
+        return ((uint32_t)(64 * nw * cw) >= cols) ? variant : 0;
+    }
+    static const Geometry full[] = {{1, 3}, {1, 5}, {1, 9}, {2, 9}, {4, 5}, {4, 9}, {8, 5}, {8, 9}};   // (NW, CW), ascending capacity
+    for (const Geometry &q : full)
+        if ((uint32_t)(64 * q.g * q.c) >= cols && !(q.c == 9 && dim > 16)) return 20000 + q.g * 100 + q.c;
+    return 0;
+}
+
 hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, std::string &err, int *status)
 {
     *status = APD_OK;
@@ -233,7 +247,18 @@ hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, 
     bool done = false;
     AlignLaunch LL = L;
     if (LL.dim < 10) LL.hybrid = 0;            // the norm expansion saves D - 4 vector ops per cell: not worth its branch below D = 10
-    if (geom_key >= 10000) {
+    if (geom_key >= 20000) {
+        const int nw = (geom_key - 20000) / 100, cw = geom_key % 100;
+        hipError_t fe = hipSuccess;
+        switch (L.dim) {
+            case 8: done = launch_full<8>(LL, nw, cw, stream, &fe); break;
+            case 10: done = launch_full<10>(LL, nw, cw, stream, &fe); break;
+            case 13: done = launch_full<13>(LL, nw, cw, stream, &fe); break;
+            case 26: done = launch_full<26>(LL, nw, cw, stream, &fe); break;
+            default: break;
+        }
+        if (done && fe != hipSuccess) return fe;
+    } else if (geom_key >= 10000) {
         const int nw = (geom_key - 10000) / 100, c = geom_key % 100;
         hipError_t we = hipSuccess;
         switch (L.dim) {

@@ -1,6 +1,8 @@
-// Instantiates the systolic and the wide fused-pair DTW kernels for frame dimension 8 (one unit per D: parallel builds).
+// Instantiates the systolic, wide and full-matrix fused-pair DTW kernels for frame dimension 8 (one unit per D: parallel builds).
 #include "dtw_wide.h"
+#include "dtw_full.h"
 namespace apd {
 template bool launch_systolic<8>(const AlignLaunch &, int, int, bool, hipStream_t);
 template bool launch_wide<8>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
+template bool launch_full<8>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
 }

@@ -292,3 +292,29 @@ def test_wide_kernel_geometries(ctx, oracle, variant, distance):
         ctx.set_distance_mode("hybrid")
         assert_parity(got, want)
         assert got[5, 8] == 0.0 and got[8, 5] == 0.0
+
+
+@pytest.mark.parametrize("variant", [0, 20103, 20105, 20109, 20209, 20405, 20409, 20805, 20809])
+@pytest.mark.parametrize("distance", ["hybrid", "exact"])
+def test_full_matrix_kernel(ctx, oracle, variant, distance):
+    """dtw_full_matrix (column strips, ONE DP for both ordered pairs): valid when the band never binds and the penalties
+    are equal -- then score(a,b) == score(b,a) in the reference itself, which the oracle confirms here bit for bit."""
+    rng = np.random.default_rng(variant + 7)
+    lens = [2, 3, 50, 64, 65, 130, 190, 191] if variant in (0, 20103, 20105) else [2, 3, 70, 130, 260, 333, 520, 571]
+    seqs = [np.cumsum(rng.standard_normal((n, 13)), axis=0).astype(np.float32) * 0.4 for n in lens]
+    seqs.append(seqs[5].copy())
+    frames = np.concatenate(seqs)
+    offsets = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint64)
+    want = oracle.align_all(frames, offsets, 1.0, 0.7, 0.7, 0.7, workers=8)
+    assert np.array_equal(want, want.T)                                  # the symmetry the kernel relies on
+    from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
+    from audio_pattern_discovery_amd.discovery import Discovery
+    ctx.set_distance_mode(distance)
+    ctx.set_variant(variant)
+    w = AlignmentWorkers.new([NDSequence(s) for s in seqs], ctx)
+    got = w.align_all(Discovery(warping_band_percentage=1.0, insertion_penalty=0.7, deletion_penalty=0.7,
+                                match_penalty=0.7)).reshape(len(seqs), len(seqs)).copy()
+    ctx.set_variant(0)
+    ctx.set_distance_mode("hybrid")
+    assert_parity(got, want)
+    assert got[5, 8] == 0.0 and got[8, 5] == 0.0
