@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libapd_oracle.so")
+_SO = os.environ.get("APD_ORACLE_LIB") or os.path.join(_HERE, "libapd_oracle.so")   # APD_ORACLE_LIB: sanitizer builds
 
 
 class OrcOp(C.Structure):
