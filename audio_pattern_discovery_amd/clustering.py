@@ -71,3 +71,23 @@ def percentile(x, perc, ctx=None):
     _lib.check(_lib.lib().apd_percentile(ctx.handle, C.c_void_p(a.ctypes.data), a.size, float(perc), 0, C.byref(v)),
                ctx.handle)
     return float(v.value)
+
+
+def dendrograms(operations, clusters, labels):
+    """The bracket strings reporting.rs:135-169 builds for TikZ-qtree, one per root that was merged at least once:
+    leaf i is rendered as labels[i] (the reference puts an \\includegraphics reference there), node k as
+    "[.k [<left> <right> ] ]".  Roots never merged are skipped, as the reference does (reporting.rs:200).
+    Lets a run be diffed against the reference's output/ (SURVEY.md 8(f) item 4)."""
+    results = {}
+    for op in operations:
+        i, j, k = op.merge_i, op.merge_j, op.into
+        if op.operation == Merge.Sequence2Sequence:
+            left, right = labels[i], labels[j]
+        elif op.operation == Merge.Sequence2Cluster:
+            left, right = labels[i], results[j]
+        elif op.operation == Merge.Cluster2Sequence:
+            left, right = results[i], labels[j]
+        else:
+            left, right = results[i], results[j]
+        results[k] = "[.%d [%s %s ] ]" % (k, left, right)
+    return {c: results[c] for c in sorted(clusters) if c in results}

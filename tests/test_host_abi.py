@@ -144,3 +144,13 @@ def test_autoencoder_bincode_layout(tmp_path):
     for bad in (blob[:-1], blob + b"\\0", blob[:5]):
         with pytest.raises(ValueError):
             AutoEncoder.from_bytes(bad)
+
+
+def test_dendrogram_bracket_strings():
+    """reporting.rs:143-168: qtree strings by Merge kind."""
+    from audio_pattern_discovery_amd.clustering import ClusteringOperation, Merge, dendrograms
+    ops = [ClusteringOperation(0, 1, 4, 0.1, Merge.Sequence2Sequence), ClusteringOperation(2, 4, 5, 0.2, Merge.Sequence2Cluster),
+           ClusteringOperation(5, 3, 6, 0.3, Merge.Cluster2Sequence)]
+    out = dendrograms(ops, {6}, ["A", "B", "C", "D"])
+    assert out == {6: "[.6 [[.5 [C [.4 [A B ] ] ] ] D ] ]"}
+    assert dendrograms(ops[:1], {2, 3, 4}, ["A", "B", "C", "D"]) == {4: "[.4 [A B ] ]"}

@@ -1,0 +1,31 @@
+"""Scale check of apd_clustering on a resident N x N matrix (run on the GPU box): python tools/upgma_scale.py 16384"""
+import ctypes as C
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from audio_pattern_discovery_amd import _lib
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+perc = float(sys.argv[2]) if len(sys.argv) > 2 else 0.05
+torch.manual_seed(0)
+x = torch.randn(n, 8, device="cuda")
+centers = torch.randn(64, 8, device="cuda") * 4
+x = x * 0.5 + centers[torch.randint(0, 64, (n,), device="cuda")]
+d = torch.cdist(x, x).contiguous()
+d.fill_diagonal_(0.0)
+ctx = _lib.Context(0)
+L = _lib.lib()
+ops = (_lib.ClusterOp * n)()
+roots = np.zeros(n, dtype=np.uint32)
+n_ops, n_roots, thr = C.c_uint32(0), C.c_uint32(0), C.c_float(0)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+_lib.check(L.apd_clustering(ctx.handle, C.c_void_p(d.data_ptr()), 1, n, perc, ops, C.byref(n_ops),
+                            roots.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n_roots), C.byref(thr)), ctx.handle)
+dt = time.perf_counter() - t0
+print("n=%d perc=%.2f merges=%d roots=%d threshold=%.4f seconds=%.3f us/merge=%.1f" %
+      (n, perc, n_ops.value, n_roots.value, thr.value, dt, dt / max(n_ops.value, 1) * 1e6))
