@@ -36,8 +36,8 @@ WORKLOADS = {
                  desc="1024 seq len~512 D=13 MFCC, Sakoe-Chiba band=32"),
     "cfg3": dict(n_seq=4096, length=1024, dim=13, pct=0.0625,
                  desc="4096 seq len~1024 D=13 MFCC, band=64, all-pairs distance matrix"),
-    "cfg4": dict(n_seq=4096, length=1024, dim=8, pct=0.0625,
-                 desc="4096 seq len~1024 D=8 autoencoder embeddings, band=64"),
+    "cfg4": dict(n_seq=4096, length=1024, dim=8, pct=0.0625, encode_from=13,
+                 desc="4096 seq len~1024, 13-dim frames -> 8-dim autoencoder embeddings on-device (neural.rs:55-71) -> DTW, band=64"),
 }
 WORKLOADS["cfg5s"] = dict(n_seq=512, length=2048, dim=13, pct=0.0625,
                           desc="512 seq len~2048 D=13, band=128 (cfg 5's per-pair shape at 1/32 of its sequence count; not a BASELINE config)")
@@ -133,7 +133,13 @@ def main():
 
     wl = WORKLOADS[args.workload]
     n, dim = wl["n_seq"], wl["dim"]
-    frames, offsets = synth.make_sequences(n, wl["length"], dim, seed=0xA9D0 + sum(map(ord, args.workload)) % 97)
+    src_dim = wl.get("encode_from", dim)
+    frames, offsets = synth.make_sequences(n, wl["length"], src_dim, seed=0xA9D0 + sum(map(ord, args.workload)) % 97)
+    enc_w = enc_b = None
+    if src_dim != dim:                                               # Mat::seeded-scale random encoder (numerics.rs:178-186)
+        rng = np.random.default_rng(0xE1C)
+        enc_w = ((rng.random((src_dim, dim)) - 0.5) / dim).astype(np.float32)
+        enc_b = ((rng.random(dim) - 0.5) / dim).astype(np.float32)
     L = _lib.lib()
     cfg = _lib.AlignConfig(wl["pct"], 1.0, 1.0, 1.0)
     pairs_all, cells_all, bytes_all = align_work(offsets, dim, cfg, 0, 1)
@@ -144,7 +150,10 @@ def main():
     ctx.set_variant(args.variant)
     ctx.set_distance_mode(args.distance, args.tau)
     ctx.set_timing(True)
-    d_frames = torch.from_numpy(frames).to(dev)                      # inputs resident in HBM
+    d_src = torch.from_numpy(frames).to(dev)                         # inputs resident in HBM
+    total_frames = int(offsets[-1])
+    d_frames = d_src if enc_w is None else torch.empty(total_frames * dim, dtype=torch.float32, device=dev)
+    f32p = C.POINTER(C.c_float)
     off_c = np.ascontiguousarray(offsets, dtype=np.uint64)
     slab_floats = int(L.apd_slab_floats(n, world))
     d_slab = torch.zeros(slab_floats, dtype=torch.float32, device=dev)
@@ -153,6 +162,9 @@ def main():
     kernel_ms = []
 
     def step():
+        if enc_w is not None:                                        # NDSequence::encoded on the whole corpus, in HBM
+            _lib.check(L.apd_encode(ctx.handle, C.c_void_p(d_src.data_ptr()), total_frames, src_dim, enc_w.ctypes.data_as(f32p),
+                                    enc_b.ctypes.data_as(f32p), dim, 1, C.c_void_p(d_frames.data_ptr())), ctx.handle)
         batch = C.c_void_p()
         _lib.check(L.apd_batch_create(ctx.handle, C.c_void_p(d_frames.data_ptr()), off_c.ctypes.data_as(C.POINTER(C.c_uint64)),
                                       n, dim, 1, C.byref(batch)), ctx.handle)
@@ -200,7 +212,8 @@ def main():
             rng = np.random.default_rng(7)
             pi = rng.integers(0, n, args.verify).astype(np.uint32)
             pj = (pi + 1 + rng.integers(0, n - 1, args.verify)).astype(np.uint32) % n
-            want, _ = oracle.align_sample(frames, offsets, pi, pj, wl["pct"], workers=host_threads())
+            ref_frames = frames if enc_w is None else oracle.encode(frames, enc_w, enc_b)
+            want, _ = oracle.align_sample(ref_frames, offsets, pi, pj, wl["pct"], workers=host_threads())
             verify = float(np.max(np.abs(result[pi, pj] - want) / np.maximum(np.abs(want), 1e-30)))
         traffic = None
         try:
@@ -241,7 +254,8 @@ def main():
                                   "threshold": float(thr.value), "percentile": 0.05,
                                   "note": "apd_clustering on the resident matrix: radix-select threshold + UPGMA (clustering.rs:81-110)"}
         if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(frames, offsets, wl, args.cpu_seconds)
+            from oracle import binding as _o
+            line["cpu_baseline"] = cpu_baseline(frames if enc_w is None else _o.encode(frames, enc_w, enc_b), offsets, wl, args.cpu_seconds)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
