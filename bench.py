@@ -41,6 +41,9 @@ WORKLOADS = {
 }
 WORKLOADS["cfg5s"] = dict(n_seq=512, length=2048, dim=13, pct=0.0625,
                           desc="512 seq len~2048 D=13, band=128 (cfg 5's per-pair shape at 1/32 of its sequence count; not a BASELINE config)")
+WORKLOADS["cfg5e"] = dict(n_seq=256, length=2048, dim=13, pct=0.0625, audio=True,
+                          desc="cfg 5's end-to-end data path at 1/64 of its sequence count: 256 recordings x 262400 i16 samples -> on-device "
+                               "cepstrum (spectrogram.rs:31-80, dft_win 256, step 128, ceps_filter 18 -> 13 bins) -> DTW band=128 (not a BASELINE config)")
 WORKLOADS["full6"] = dict(n_seq=256, length=600, dim=13, pct=1.0,
                           desc="256 seq len~600 D=13, full DTW (the reference's shipped warping_band_percentage = 1.0 on long slices; not a BASELINE config)")
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -134,7 +137,20 @@ def main():
     wl = WORKLOADS[args.workload]
     n, dim = wl["n_seq"], wl["dim"]
     src_dim = wl.get("encode_from", dim)
-    frames, offsets = synth.make_sequences(n, wl["length"], src_dim, seed=0xA9D0 + sum(map(ord, args.workload)) % 97)
+    audio = None
+    if wl.get("audio"):
+        # synthetic recordings; the frames the CPU legs use come from the oracle's cepstrum of the same audio
+        from oracle import binding as _orc
+        rng_a = np.random.default_rng(0xA0D10)
+        n_samp = 256 + 128 * wl["length"]
+        base = [synth.make_audio(n_samp, seed=1000 + k) for k in range(16)]
+        audio = [np.clip(base[k % 16].astype(np.int32) + rng_a.integers(-200 * (k // 16), 200 * (k // 16) + 1, n_samp), -32768, 32767).astype(np.int16)
+                 for k in range(n)]
+    frames, offsets = (None, None) if audio is not None else synth.make_sequences(n, wl["length"], src_dim, seed=0xA9D0 + sum(map(ord, args.workload)) % 97)
+    if audio is not None:
+        s_off = np.concatenate([[0], np.cumsum([len(a) for a in audio])]).astype(np.uint64)
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum([(len(a) - 256 + 127) // 128 for a in audio])
     enc_w = enc_b = None
     if src_dim != dim:                                               # Mat::seeded-scale random encoder (numerics.rs:178-186)
         rng = np.random.default_rng(0xE1C)
@@ -150,8 +166,14 @@ def main():
     ctx.set_variant(args.variant)
     ctx.set_distance_mode(args.distance, args.tau)
     ctx.set_timing(True)
-    d_src = torch.from_numpy(frames).to(dev)                         # inputs resident in HBM
     total_frames = int(offsets[-1])
+    if audio is not None:
+        d_audio = torch.from_numpy(np.concatenate(audio)).to(dev)    # inputs resident in HBM
+        d_src = torch.empty(total_frames * dim, dtype=torch.float32, device=dev)
+        f_off = np.zeros(n + 1, dtype=np.uint64)
+        nb = C.c_uint32(0)
+    else:
+        d_src = torch.from_numpy(frames).to(dev)                     # inputs resident in HBM
     d_frames = d_src if enc_w is None else torch.empty(total_frames * dim, dtype=torch.float32, device=dev)
     f32p = C.POINTER(C.c_float)
     off_c = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -162,6 +184,10 @@ def main():
     kernel_ms = []
 
     def step():
+        if audio is not None:                                        # NDSequence::new on the whole corpus, in HBM
+            _lib.check(L.apd_cepstrum_batch(ctx.handle, C.c_void_p(d_audio.data_ptr()), s_off.ctypes.data_as(C.POINTER(C.c_uint64)), n,
+                                            256, 128, 18, 1, C.c_void_p(d_src.data_ptr()), f_off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                            C.byref(nb)), ctx.handle)
         if enc_w is not None:                                        # NDSequence::encoded on the whole corpus, in HBM
             _lib.check(L.apd_encode(ctx.handle, C.c_void_p(d_src.data_ptr()), total_frames, src_dim, enc_w.ctypes.data_as(f32p),
                                     enc_b.ctypes.data_as(f32p), dim, 1, C.c_void_p(d_frames.data_ptr())), ctx.handle)
@@ -212,8 +238,17 @@ def main():
             rng = np.random.default_rng(7)
             pi = rng.integers(0, n, args.verify).astype(np.uint32)
             pj = (pi + 1 + rng.integers(0, n - 1, args.verify)).astype(np.uint32) % n
-            ref_frames = frames if enc_w is None else oracle.encode(frames, enc_w, enc_b)
-            want, _ = oracle.align_sample(ref_frames, offsets, pi, pj, wl["pct"], workers=host_threads())
+            if audio is not None:                                    # oracle cepstrum of the sampled recordings only
+                need = sorted(set(pi.tolist()) | set(pj.tolist()))
+                remap = {s_: k for k, s_ in enumerate(need)}
+                feats = [oracle.cepstrum(audio[s_], 256, 128, 18) for s_ in need]
+                ref_frames = np.concatenate(feats)
+                ref_off = np.concatenate([[0], np.cumsum([len(f) for f in feats])]).astype(np.uint64)
+                want, _ = oracle.align_sample(ref_frames, ref_off, np.array([remap[v] for v in pi.tolist()], np.uint32),
+                                              np.array([remap[v] for v in pj.tolist()], np.uint32), wl["pct"], workers=host_threads())
+            else:
+                ref_frames = frames if enc_w is None else oracle.encode(frames, enc_w, enc_b)
+                want, _ = oracle.align_sample(ref_frames, offsets, pi, pj, wl["pct"], workers=host_threads())
             verify = float(np.max(np.abs(result[pi, pj] - want) / np.maximum(np.abs(want), 1e-30)))
         traffic = None
         try:
@@ -240,7 +275,7 @@ def main():
                          "kernel": "dtw_fused (rank 0 share: %d ordered pairs)" % pairs_r,
                          "kernel_ms": k_ms, "alg_bytes_per_launch": bytes_r,
                          "kernel_cells_per_s": cells_r / (k_ms * 1e-3)},
-            "max_rel_err_vs_oracle": verify, "parity_ok": (verify is None) or bool(verify <= 1e-4),
+            "max_rel_err_vs_oracle": verify, "parity_ok": (verify is None) or bool(verify <= (1e-3 if audio is not None else 1e-4)),
         }
         if args.cluster:
             ops = (_lib.ClusterOp * n)()
@@ -253,7 +288,9 @@ def main():
             line["clustering"] = {"seconds": time.perf_counter() - t0, "merges": int(n_ops.value), "roots": int(n_roots.value),
                                   "threshold": float(thr.value), "percentile": 0.05,
                                   "note": "apd_clustering on the resident matrix: radix-select threshold + UPGMA (clustering.rs:81-110)"}
-        if world == 1 and args.cpu_seconds > 0:
+        if world == 1 and args.cpu_seconds > 0 and audio is not None:
+            line["cpu_baseline"] = None                              # the CPU legs would need the whole corpus' cepstra on the host
+        elif world == 1 and args.cpu_seconds > 0:
             from oracle import binding as _o
             line["cpu_baseline"] = cpu_baseline(frames if enc_w is None else _o.encode(frames, enc_w, enc_b), offsets, wl, args.cpu_seconds)
         else:
