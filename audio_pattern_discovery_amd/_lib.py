@@ -75,9 +75,10 @@ SYMBOLS = [
     ("apd_rank_tiles", C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint32]),
     ("apd_slab_floats", C.c_uint64, [C.c_uint32, C.c_uint32]),
     ("apd_align_tiles_async", C.c_int, [_vp, _vp, C.POINTER(AlignConfig), C.c_uint32, C.c_uint32, _vp]),
-    ("apd_unpack_tiles_async", C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _vp]),
+    ("apd_unpack_tiles_async", C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp]),
+    ("apd_length_order", C.c_int, [_u64p, C.c_uint32, _u32p]),
     ("apd_rank_tile_list", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _u32p, C.c_uint64, _u64p]),
-    ("apd_unpack_tiles_host", C.c_int, [C.c_uint32, C.c_uint32, _f32p, _f32p]),
+    ("apd_unpack_tiles_host", C.c_int, [_u64p, C.c_uint32, C.c_uint32, _f32p, _f32p]),
     ("apd_align_work", C.c_int, [_u64p, C.c_uint32, C.c_uint32, C.POINTER(AlignConfig), C.c_uint32, C.c_uint32,
                                  _u64p, _u64p, _u64p]),
     ("apd_align_pair", C.c_int, [_vp, _f32p, C.c_uint64, _f32p, C.c_uint64, C.c_uint32,

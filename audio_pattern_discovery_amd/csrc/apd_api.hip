@@ -43,6 +43,17 @@ void rank_tile_list(uint32_t n_seq, uint32_t rank, uint32_t world, std::vector<u
             if (g % world == rank) out.push_back(make_uint2(ta, tb));
 }
 
+// Resident / tiling order: position p holds sequence order[p]; longest first, equal lengths by ascending index.  Pure
+// function of the lengths, so every rank derives the same order.
+void length_order(const uint64_t *offsets, uint32_t n_seq, std::vector<uint32_t> &order)
+{
+    order.resize(n_seq);
+    for (uint32_t s = 0; s < n_seq; ++s) order[s] = s;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return offsets[a + 1] - offsets[a] > offsets[b + 1] - offsets[b];
+    });
+}
+
 // cells visited by alignments.rs:174-175 for lengths (n, m) and half-width w:
 // #{(i,j) in [1,n]x[1,m] : -w <= j-i <= w-1}
 uint64_t tri_count(uint64_t n, uint64_t m, uint64_t k)   // #{(i,j): j - i >= k}, k >= 0
@@ -211,10 +222,7 @@ extern "C" int apd_batch_create(apd_context *ctx, const float *frames, const uin
     apd_batch *b = new (std::nothrow) apd_batch();
     if (!b) return APD_ERR_OOM;
     b->ctx = ctx; b->n_seq = n_seq; b->dim = dim; b->dpad = (dim + 4) & ~3u;   /* dim components + squared norm, padded to 16 bytes */ b->total_frames = total;
-    b->offsets.assign(offsets, offsets + n_seq + 1);
     b->min_len = 0xFFFFFFFFu; b->max_len = 0;
-    std::vector<uint32_t> off32(n_seq + 1);
-    for (uint32_t s = 0; s <= n_seq; ++s) off32[s] = (uint32_t)offsets[s] + 2 * s;   // two sentinel frames behind every sequence
     for (uint32_t s = 0; s < n_seq; ++s) {
         if (offsets[s + 1] < offsets[s]) { delete b; return APD_ERR_INVALID_ARG; }
         const uint32_t len = (uint32_t)(offsets[s + 1] - offsets[s]);
@@ -222,13 +230,29 @@ extern "C" int apd_batch_create(apd_context *ctx, const float *frames, const uin
         b->max_len = std::max(b->max_len, len);
     }
     if (n_seq == 0) b->min_len = 0;
+    // Resident order: longest sequence first (length_order), so that the 16 sequences of a tile row have like lengths --
+    // one kernel geometry fits the whole tile -- and the most expensive tiles of a launch start first.
+    length_order(offsets, n_seq, b->order);
+    b->offsets.assign(n_seq + 1, 0);                                     // offsets of the RESIDENT order
+    std::vector<uint32_t> off32(n_seq + 1), src32(n_seq + 1, 0);
+    for (uint32_t p = 0; p < n_seq; ++p) {
+        b->offsets[p + 1] = b->offsets[p] + (offsets[b->order[p] + 1] - offsets[b->order[p]]);
+        src32[p] = (uint32_t)offsets[b->order[p]];
+    }
+    for (uint32_t p = 0; p <= n_seq; ++p) off32[p] = (uint32_t)b->offsets[p] + 2 * p;   // two sentinel frames behind every sequence
     auto fail = [&](int rc) { apd_batch_destroy(b); return rc; };
     const uint64_t padded_frames = total + 2ull * n_seq;
     const size_t padded_bytes = std::max<size_t>((size_t)padded_frames * b->dpad * sizeof(float), 16);
     b->frames_bytes = padded_bytes < 0xFFFFFE00ull ? (uint32_t)padded_bytes : 0u;
     if (hipMalloc((void **)&b->d_frames, padded_bytes) != hipSuccess) return fail(APD_ERR_OOM);
     if (hipMalloc((void **)&b->d_seq_off, (n_seq + 1) * sizeof(uint32_t)) != hipSuccess) return fail(APD_ERR_OOM);
+    if (hipMalloc((void **)&b->d_src_off, (n_seq + 1) * sizeof(uint32_t)) != hipSuccess) return fail(APD_ERR_OOM);
+    if (hipMalloc((void **)&b->d_order, (n_seq + 1) * sizeof(uint32_t)) != hipSuccess) return fail(APD_ERR_OOM);
     if (hipMemcpyAsync(b->d_seq_off, off32.data(), (n_seq + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return fail(APD_ERR_HIP);
+    if (hipMemcpyAsync(b->d_src_off, src32.data(), (n_seq + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return fail(APD_ERR_HIP);
+    if (n_seq && hipMemcpyAsync(b->d_order, b->order.data(), n_seq * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         return fail(APD_ERR_HIP);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(APD_ERR_HIP);    // off32 is a stack-lifetime buffer
     if (padded_frames > 0) {
@@ -242,7 +266,7 @@ extern "C" int apd_batch_create(apd_context *ctx, const float *frames, const uin
             }
             d_src = d_tmp;
         }
-        hipError_t e = launch_pad(d_src, b->d_frames, b->d_seq_off, n_seq, padded_frames, dim, b->dpad, ctx->stream);
+        hipError_t e = launch_pad(d_src, b->d_frames, b->d_seq_off, b->d_src_off, n_seq, padded_frames, dim, b->dpad, ctx->stream);
         if (d_tmp) { hipStreamSynchronize(ctx->stream); hipFree(d_tmp); }
         if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return fail(APD_ERR_HIP); }
     }
@@ -257,6 +281,8 @@ extern "C" int apd_batch_destroy(apd_batch *b)
     for (auto &kv : b->tile_cache) hipFree(kv.second.d_tiles);
     if (b->d_frames) hipFree(b->d_frames);
     if (b->d_seq_off) hipFree(b->d_seq_off);
+    if (b->d_src_off) hipFree(b->d_src_off);
+    if (b->d_order) hipFree(b->d_order);
     delete b;
     return APD_OK;
 }
@@ -301,9 +327,20 @@ extern "C" int apd_rank_tile_list(uint32_t n_seq, uint32_t rank, uint32_t world,
     return APD_OK;
 }
 
-extern "C" int apd_unpack_tiles_host(uint32_t n_seq, uint32_t world, const float *gathered, float *out)
+extern "C" int apd_length_order(const uint64_t *offsets, uint32_t n_seq, uint32_t *order)
 {
-    if (world == 0 || (n_seq && (!gathered || !out))) return APD_ERR_INVALID_ARG;
+    if (!offsets || (n_seq && !order)) return APD_ERR_INVALID_ARG;
+    std::vector<uint32_t> o;
+    length_order(offsets, n_seq, o);
+    std::copy(o.begin(), o.end(), order);
+    return APD_OK;
+}
+
+extern "C" int apd_unpack_tiles_host(const uint64_t *offsets, uint32_t n_seq, uint32_t world, const float *gathered, float *out)
+{
+    if (!offsets || world == 0 || (n_seq && (!gathered || !out))) return APD_ERR_INVALID_ARG;
+    std::vector<uint32_t> order;
+    length_order(offsets, n_seq, order);
     const uint64_t slab = apd_slab_floats(n_seq, world);
     std::memset(out, 0, (size_t)n_seq * n_seq * sizeof(float));                 // alignments.rs:21-23
     const uint32_t side = tiles_side(n_seq);
@@ -313,8 +350,9 @@ extern "C" int apd_unpack_tiles_host(uint32_t n_seq, uint32_t world, const float
             const float *t = gathered + (g % world) * slab + (g / world) * 2 * kSlotsPerTile;
             for (uint32_t sa = 0; sa < kTile; ++sa)
                 for (uint32_t sb = 0; sb < kTile; ++sb) {
-                    const uint32_t a = ta * kTile + sa, b = tb * kTile + sb;
-                    if (a < b && b < n_seq) {
+                    const uint32_t pa = ta * kTile + sa, pb = tb * kTile + sb;   // positions in the resident order
+                    if (pa < pb && pb < n_seq) {
+                        const uint32_t a = order[pa], b = order[pb];
                         out[(uint64_t)a * n_seq + b] = t[sa * kTile + sb];
                         out[(uint64_t)b * n_seq + a] = t[kSlotsPerTile + sa * kTile + sb];
                     }
@@ -420,13 +458,14 @@ extern "C" int apd_align_tiles_async(apd_context *ctx, const apd_batch *batch, c
     return align_tiles_impl(ctx, batch, band_from_cfg(cfg), rank, world, d_slab);
 }
 
-extern "C" int apd_unpack_tiles_async(apd_context *ctx, uint32_t n_seq, uint32_t world, const float *d_gathered,
+extern "C" int apd_unpack_tiles_async(apd_context *ctx, const apd_batch *batch, uint32_t world, const float *d_gathered,
                                       float *d_out)
 {
-    if (!ctx || !d_gathered || !d_out || world == 0) return APD_ERR_INVALID_ARG;
+    if (!ctx || !batch || batch->ctx != ctx || !d_gathered || !d_out || world == 0) return APD_ERR_INVALID_ARG;
+    const uint32_t n_seq = batch->n_seq;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemsetAsync(d_out, 0, (size_t)n_seq * n_seq * sizeof(float), ctx->stream));   // alignments.rs:21-23
-    HIP_TRY(ctx, launch_unpack(d_gathered, d_out, n_seq, world, apd_slab_floats(n_seq, world), ctx->stream));
+    HIP_TRY(ctx, launch_unpack(d_gathered, d_out, batch->d_order, n_seq, world, apd_slab_floats(n_seq, world), ctx->stream));
     return APD_OK;
 }
 
@@ -438,7 +477,7 @@ static int align_all_device_impl(apd_context *ctx, const apd_batch *batch, const
     if (rc) return rc;
     rc = align_tiles_impl(ctx, batch, band, 0, 1, (float *)ctx->ws_slab);
     if (rc) return rc;
-    return apd_unpack_tiles_async(ctx, batch->n_seq, 1, (const float *)ctx->ws_slab, d_out);
+    return apd_unpack_tiles_async(ctx, batch, 1, (const float *)ctx->ws_slab, d_out);
 }
 
 extern "C" int apd_align_all_device_async(apd_context *ctx, const apd_batch *batch, const apd_align_config *cfg,
@@ -508,12 +547,15 @@ extern "C" int apd_align_work(const uint64_t *offsets, uint32_t n_seq, uint32_t 
     const BandSpec band = band_from_cfg(cfg);
     std::vector<uint2> tiles;
     rank_tile_list(n_seq, rank, world, tiles);
+    std::vector<uint32_t> order;
+    length_order(offsets, n_seq, order);                                  // tiles are cut from the resident order
     uint64_t np = 0, nc = 0, nb = 0;
     for (const uint2 &t : tiles)
         for (uint32_t sa = 0; sa < kTile; ++sa)
             for (uint32_t sb = 0; sb < kTile; ++sb) {
-                const uint32_t a = t.x * kTile + sa, b = t.y * kTile + sb;
-                if (!(a < b && b < n_seq)) continue;
+                const uint32_t pa = t.x * kTile + sa, pb = t.y * kTile + sb;
+                if (!(pa < pb && pb < n_seq)) continue;
+                const uint32_t a = order[pa], b = order[pb];
                 const uint64_t n = offsets[a + 1] - offsets[a], m = offsets[b + 1] - offsets[b];
                 if (n == 0 || m == 0) return APD_ERR_EMPTY_SEQUENCE;
                 const uint64_t mx = std::max(n, m), gap = mx - std::min(n, m);

@@ -47,9 +47,9 @@ hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, 
 int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen);
 // >= 20000: full-matrix kernel, 20000 + NW * 100 + CW, for `cols` columns (0 if none fits)
 int pick_full_key(uint32_t cols, uint32_t dim, int variant);   // >= 10000: wide kernel, 10000 + NW * 100 + C
-hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_off, uint32_t n_seq, uint64_t n_frames_padded,
-                      uint32_t dim, uint32_t dpad, hipStream_t stream);
-hipError_t launch_unpack(const float *d_gathered, float *d_out, uint32_t n_seq, uint32_t world,
+hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_off, const uint32_t *d_src_off, uint32_t n_seq,
+                      uint64_t n_frames_padded, uint32_t dim, uint32_t dpad, hipStream_t stream);
+hipError_t launch_unpack(const float *d_gathered, float *d_out, const uint32_t *d_order, uint32_t n_seq, uint32_t world,
                          uint64_t slab_floats, hipStream_t stream);
 hipError_t launch_selftest(int *d_result, hipStream_t stream);
 
@@ -99,7 +99,10 @@ struct apd_batch {
     float *d_frames = nullptr;        // padded layout with sentinels (see dtw_generic.hip)
     uint32_t frames_bytes = 0;
     uint32_t *d_seq_off = nullptr;
-    std::vector<uint64_t> offsets;    // host copy
+    uint32_t *d_src_off = nullptr;    // first frame of resident sequence p in the caller's frame array
+    uint32_t *d_order = nullptr;      // resident position p -> caller's sequence index
+    std::vector<uint32_t> order;      // host copy of d_order
+    std::vector<uint64_t> offsets;    // frame offsets of the RESIDENT order (host)
     uint32_t min_len = 0, max_len = 0;
     // device-resident tile lists, grouped by the kernel geometry each tile needs
     struct TileClass { int geom_key; uint32_t first, count, w_max; };

@@ -101,12 +101,13 @@ __global__ __launch_bounds__(64) void dtw_fused_generic(const AlignLaunch L, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// Resident layout: per sequence [frames | sentinel H | sentinel E], seq_off[s] = offsets[s] + 2 s.  A frame is dpad =
+// Resident layout: sequences in length order (apd_length_order), per sequence [frames | sentinel H | sentinel E],
+// seq_off[p] = resident_offsets[p] + 2 p; src_off[p] = first frame of that sequence in the caller's array.  A frame is dpad =
 // ceil4(dim + 1) floats: the dim components, then the squared norm sum_k x_k^2 (slot dim), then zeros.  Sentinel H has
 // zero components and norm +INF (hybrid distances), sentinel E has +INF components (difference-form distances).
 // ------------------------------------------------------------------------------------------------
 __global__ void pad_frames_kernel(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ seq_off,
-                                  uint32_t n_seq, uint64_t n_frames_padded, uint32_t dim, uint32_t dpad)
+                                  const uint32_t *__restrict__ src_off, uint32_t n_seq, uint64_t n_frames_padded, uint32_t dim, uint32_t dpad)
 {
     const uint64_t total = n_frames_padded * dpad;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
@@ -119,7 +120,7 @@ __global__ void pad_frames_kernel(const float *__restrict__ src, float *__restri
         if (sent_e) v = (k <= dim) ? APD_INF : 0.0f;
         else if (sent_h) v = (k == dim) ? APD_INF : 0.0f;
         else {
-            const float *fr = src + (uint64_t)(f - 2 * lo) * dim;
+            const float *fr = src + (uint64_t)(src_off[lo] + (f - seq_off[lo])) * dim;
             if (k < dim) v = fr[k];
             else if (k == dim) { double acc = 0.0; for (uint32_t t = 0; t < dim; ++t) acc += (double)fr[t] * (double)fr[t]; v = (float)acc; }
         }
@@ -128,8 +129,8 @@ __global__ void pad_frames_kernel(const float *__restrict__ src, float *__restri
 }
 
 // gathered: `world` slabs of slab_floats each; slab r holds tiles r, r+world, ... in order.
-__global__ void unpack_tiles_kernel(const float *__restrict__ gathered, float *__restrict__ out, uint32_t n_seq,
-                                    uint32_t world, uint64_t slab_floats, uint32_t n_tiles_side)
+__global__ void unpack_tiles_kernel(const float *__restrict__ gathered, float *__restrict__ out,
+                                    const uint32_t *__restrict__ order, uint32_t n_seq, uint32_t world, uint64_t slab_floats, uint32_t n_tiles_side)
 {
     const uint32_t g = blockIdx.x;                            // (ta, tb), ta <= tb, row-major over the upper triangle
     uint32_t ta = 0, rem = g, row = n_tiles_side;
@@ -138,8 +139,9 @@ __global__ void unpack_tiles_kernel(const float *__restrict__ gathered, float *_
     const uint32_t rank = g % world, local = g / world;
     const float *slab = gathered + (uint64_t)rank * slab_floats + (uint64_t)local * 2 * kSlotsPerTile;
     const int sa = threadIdx.x / kTile, sb = threadIdx.x % kTile;
-    const uint32_t a = ta * kTile + sa, b = tb * kTile + sb;
-    if (a < b && b < n_seq) {
+    const uint32_t pa = ta * kTile + sa, pb = tb * kTile + sb;   // positions in the resident (length) order
+    if (pa < pb && pb < n_seq) {
+        const uint32_t a = order[pa], b = order[pb];
         out[(uint64_t)a * n_seq + b] = slab[sa * kTile + sb];
         out[(uint64_t)b * n_seq + a] = slab[kSlotsPerTile + sa * kTile + sb];
     }
@@ -166,25 +168,25 @@ hipError_t launch_selftest(int *d_result, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_off, uint32_t n_seq, uint64_t n_frames_padded,
-                      uint32_t dim, uint32_t dpad, hipStream_t stream)
+hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_off, const uint32_t *d_src_off, uint32_t n_seq,
+                      uint64_t n_frames_padded, uint32_t dim, uint32_t dpad, hipStream_t stream)
 {
     if (n_frames_padded == 0) return hipSuccess;
     const uint64_t total = n_frames_padded * dpad;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 16384);
-    hipLaunchKernelGGL(pad_frames_kernel, dim3(blocks), dim3(256), 0, stream, d_src, d_dst, d_seq_off, n_seq, n_frames_padded,
+    hipLaunchKernelGGL(pad_frames_kernel, dim3(blocks), dim3(256), 0, stream, d_src, d_dst, d_seq_off, d_src_off, n_seq, n_frames_padded,
                        dim, dpad);
     return hipGetLastError();
 }
 
-hipError_t launch_unpack(const float *d_gathered, float *d_out, uint32_t n_seq, uint32_t world, uint64_t slab_floats,
-                         hipStream_t stream)
+hipError_t launch_unpack(const float *d_gathered, float *d_out, const uint32_t *d_order, uint32_t n_seq, uint32_t world,
+                         uint64_t slab_floats, hipStream_t stream)
 {
     const uint32_t side = (n_seq + kTile - 1) / kTile;
     const uint64_t n_tiles = (uint64_t)side * (side + 1) / 2;
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(unpack_tiles_kernel, dim3((uint32_t)n_tiles), dim3(kSlotsPerTile), 0, stream, d_gathered, d_out,
-                       n_seq, world, slab_floats, side);
+                       d_order, n_seq, world, slab_floats, side);
     return hipGetLastError();
 }
 

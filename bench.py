@@ -44,6 +44,9 @@ WORKLOADS["cfg5s"] = dict(n_seq=512, length=2048, dim=13, pct=0.0625,
 WORKLOADS["cfg5e"] = dict(n_seq=256, length=2048, dim=13, pct=0.0625, audio=True,
                           desc="cfg 5's end-to-end data path at 1/64 of its sequence count: 256 recordings x 262400 i16 samples -> on-device "
                                "cepstrum (spectrogram.rs:31-80, dft_win 256, step 128, ceps_filter 18 -> 13 bins) -> DTW band=128 (not a BASELINE config)")
+WORKLOADS["ship"] = dict(n_seq=512, length=525, jitter=375, dim=10, pct=1.0, encode_from=26,
+                         desc="the reference's shipped Discovery.toml shape: 512 ragged VAT slices of 150..900 frames, 26-bin cepstra -> "
+                              "10-dim autoencoder embeddings on-device -> full DTW (warping_band_percentage = 1.0); not a BASELINE config")
 WORKLOADS["full6"] = dict(n_seq=256, length=600, dim=13, pct=1.0,
                           desc="256 seq len~600 D=13, full DTW (the reference's shipped warping_band_percentage = 1.0 on long slices; not a BASELINE config)")
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -146,7 +149,7 @@ def main():
         base = [synth.make_audio(n_samp, seed=1000 + k) for k in range(16)]
         audio = [np.clip(base[k % 16].astype(np.int32) + rng_a.integers(-200 * (k // 16), 200 * (k // 16) + 1, n_samp), -32768, 32767).astype(np.int16)
                  for k in range(n)]
-    frames, offsets = (None, None) if audio is not None else synth.make_sequences(n, wl["length"], src_dim, seed=0xA9D0 + sum(map(ord, args.workload)) % 97)
+    frames, offsets = (None, None) if audio is not None else synth.make_sequences(n, wl["length"], src_dim, seed=0xA9D0 + sum(map(ord, args.workload)) % 97, jitter=wl.get("jitter"))
     if audio is not None:
         s_off = np.concatenate([[0], np.cumsum([len(a) for a in audio])]).astype(np.uint64)
         offsets = np.zeros(n + 1, dtype=np.uint64)
@@ -202,7 +205,7 @@ def main():
             host = torch.empty(slab_floats * world, dtype=torch.float32)
             dist.all_gather_into_tensor(host, d_slab.cpu())          # rehearsal path only
             d_gathered.copy_(host)
-        _lib.check(L.apd_unpack_tiles_async(ctx.handle, n, world, C.c_void_p(d_gathered.data_ptr()),
+        _lib.check(L.apd_unpack_tiles_async(ctx.handle, batch, world, C.c_void_p(d_gathered.data_ptr()),
                                             C.c_void_p(d_out.data_ptr())), ctx.handle)
         return batch
 

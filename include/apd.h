@@ -111,23 +111,28 @@ int apd_align_all_device_async(apd_context *ctx, const apd_batch *batch, const a
                                float *d_out);
 
 /* Sharded form (the reference's static row blocks, alignments.rs:33-37, become pair tiles):
- * the upper triangle of the n x n pair matrix is cut into apd_tile_size() x apd_tile_size()
- * tiles; rank r of `world` owns tiles r, r+world, ...  Each rank fills one packed slab of
- * apd_slab_floats() floats; after an all-gather of the `world` slabs (rank order) into
- * d_gathered, apd_unpack_tiles_async scatters them into the n x n matrix. */
+ * the sequences are taken in LENGTH ORDER (apd_length_order: longest first, equal lengths by
+ * ascending index -- a batch keeps them resident in that order), and the upper triangle of the
+ * n x n pair matrix over those positions is cut into apd_tile_size() x apd_tile_size() tiles, so
+ * that the sequences of a tile have like lengths; rank r of `world` owns tiles r, r+world, ...
+ * Each rank fills one packed slab of apd_slab_floats() floats; after an all-gather of the `world`
+ * slabs (rank order) into d_gathered, apd_unpack_tiles_async scatters them into the n x n matrix
+ * indexed by the caller's sequence numbers. */
 uint32_t apd_tile_size(void);
 uint64_t apd_num_tiles(uint32_t n_seq);
 uint64_t apd_rank_tiles(uint32_t n_seq, uint32_t rank, uint32_t world);
 uint64_t apd_slab_floats(uint32_t n_seq, uint32_t world);
 int apd_align_tiles_async(apd_context *ctx, const apd_batch *batch, const apd_align_config *cfg,
                           uint32_t rank, uint32_t world, float *d_slab);
-int apd_unpack_tiles_async(apd_context *ctx, uint32_t n_seq, uint32_t world, const float *d_gathered,
+int apd_unpack_tiles_async(apd_context *ctx, const apd_batch *batch, uint32_t world, const float *d_gathered,
                            float *d_out);
-/* Host-side views of the same sharding (no GPU needed): the (tile_a, tile_b) list of a rank, 2 uint32 per tile,
- * and the scatter of gathered slabs held in HOST memory (for a host that gathers over its own transport). */
+/* Host-side views of the same sharding (no GPU needed): the length order (order[p] = sequence at position p), the
+ * (tile_a, tile_b) list of a rank over those positions, 2 uint32 per tile, and the scatter of gathered slabs held in
+ * HOST memory (for a host that gathers over its own transport). */
+int apd_length_order(const uint64_t *offsets, uint32_t n_seq, uint32_t *order);
 int apd_rank_tile_list(uint32_t n_seq, uint32_t rank, uint32_t world, uint32_t *tile_ab, uint64_t capacity,
                        uint64_t *n_tiles);
-int apd_unpack_tiles_host(uint32_t n_seq, uint32_t world, const float *gathered, float *out);
+int apd_unpack_tiles_host(const uint64_t *offsets, uint32_t n_seq, uint32_t world, const float *gathered, float *out);
 
 /* Work accounting for the metric: cells = sum over ordered pairs of the
  * cells alignments.rs:174-175 visits; alg_bytes = sum of 4*dim*(n+m)+4. */

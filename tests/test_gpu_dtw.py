@@ -164,7 +164,7 @@ def test_sharded_tiles_equal_single_launch(ctx, apd, oracle):
         apd.check(L.apd_align_tiles_async(ctx.handle, batch.handle, C.byref(cfg), r, world,
                                           C.c_void_p(gathered.data_ptr() + 4 * r * slab)), ctx.handle)
     out = torch.empty(n * n, dtype=torch.float32, device="cuda")
-    apd.check(L.apd_unpack_tiles_async(ctx.handle, n, world, C.c_void_p(gathered.data_ptr()), C.c_void_p(out.data_ptr())),
+    apd.check(L.apd_unpack_tiles_async(ctx.handle, batch.handle, world, C.c_void_p(gathered.data_ptr()), C.c_void_p(out.data_ptr())),
               ctx.handle)
     ctx.synchronize()
     assert_parity(out.cpu().numpy().reshape(n, n), oracle.align_all(frames, offsets, 0.0625, workers=8))
@@ -229,7 +229,7 @@ def test_full_size_properties_cfg3(ctx, oracle):
         _lib.check(L.apd_align_tiles_async(ctx.handle, batch.handle, C.byref(cfg), r, world,
                                            C.c_void_p(gathered.data_ptr() + 4 * r * slab)), ctx.handle)
     out2 = torch.empty(n * n, dtype=torch.float32, device="cuda")
-    _lib.check(L.apd_unpack_tiles_async(ctx.handle, n, world, C.c_void_p(gathered.data_ptr()), C.c_void_p(out2.data_ptr())), ctx.handle)
+    _lib.check(L.apd_unpack_tiles_async(ctx.handle, batch.handle, world, C.c_void_p(gathered.data_ptr()), C.c_void_p(out2.data_ptr())), ctx.handle)
     ctx.synchronize()
     assert torch.equal(out, out2)
 

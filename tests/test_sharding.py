@@ -17,12 +17,14 @@ def oracle_slab(oracle, frames, offsets, pct, rank, world):
     t = sharding.tile_size()
     slab = np.zeros(sharding.slab_floats(n, world), dtype=np.float32)
     seqs = synth.split(frames, offsets)
+    order = sharding.length_order(offsets)                       # tiles are cut over the length-sorted positions
     for k, (ta, tb) in enumerate(sharding.rank_tiles(n, rank, world)):
         blk = slab[k * 2 * t * t:(k + 1) * 2 * t * t].reshape(2, t, t)
         for sa in range(t):
             for sb in range(t):
-                a, b = int(ta) * t + sa, int(tb) * t + sb
-                if a < b < n:
+                pa, pb = int(ta) * t + sa, int(tb) * t + sb
+                if pa < pb < n:
+                    a, b = int(order[pa]), int(order[pb])
                     band = oracle.warping_band(pct, max(len(seqs[a]), len(seqs[b])))
                     blk[0, sa, sb] = oracle.dtw_pair(seqs[a], seqs[b], band)
                     blk[1, sa, sb] = oracle.dtw_pair(seqs[b], seqs[a], band)
@@ -48,7 +50,7 @@ def test_emulated_three_ranks_reassemble_the_matrix(oracle):
     frames, offsets = synth.make_sequences(37, 20, 5, seed=3, jitter=6)
     want = oracle.align_all(frames, offsets, 0.25, workers=4)
     gathered = np.concatenate([oracle_slab(oracle, frames, offsets, 0.25, r, 3) for r in range(3)])
-    got = sharding.unpack_host(37, 3, gathered)
+    got = sharding.unpack_host(offsets, 3, gathered)
     assert np.array_equal(got, want)
 
 
@@ -62,7 +64,7 @@ def _worker(rank, world, port, q):
     gathered = torch.empty(world * slab.numel(), dtype=torch.float32)
     dist.all_gather_into_tensor(gathered, slab)                                 # the one collective of the path
     if rank == 0:
-        got = sharding.unpack_host(35, world, gathered.numpy())
+        got = sharding.unpack_host(offsets, world, gathered.numpy())
         want = oracle.align_all(frames, offsets, 0.0625, workers=2)
         q.put(bool(np.array_equal(got, want)))
     dist.barrier()
@@ -84,3 +86,11 @@ def test_gloo_world_size_2_all_gather_and_unpack():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_length_order_is_longest_first_and_stable():
+    lens = np.array([5, 9, 5, 1, 9, 7, 5], dtype=np.uint64)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    order = sharding.length_order(offsets)
+    assert order.tolist() == [1, 4, 5, 0, 2, 6, 3]            # equal lengths keep ascending index
+    assert sharding.length_order(np.zeros(1, dtype=np.uint64)).tolist() == []
