@@ -221,7 +221,8 @@ extern "C" int apd_batch_create(apd_context *ctx, const float *frames, const uin
     if (total + 2ull * n_seq >= (1ull << 32) || offsets[0] != 0) return APD_ERR_INVALID_ARG;
     apd_batch *b = new (std::nothrow) apd_batch();
     if (!b) return APD_ERR_OOM;
-    b->ctx = ctx; b->n_seq = n_seq; b->dim = dim; b->dpad = (dim + 4) & ~3u;   /* dim components + squared norm, padded to 16 bytes */ b->total_frames = total;
+    // resident frames carry kernel_dim(dim) >= dim components (zero fill: distances unchanged, dtw_common.h), then the squared norm
+    b->ctx = ctx; b->n_seq = n_seq; b->src_dim = dim; b->dim = kernel_dim(dim); b->dpad = (b->dim + 4) & ~3u; b->total_frames = total;
     b->min_len = 0xFFFFFFFFu; b->max_len = 0;
     for (uint32_t s = 0; s < n_seq; ++s) {
         if (offsets[s + 1] < offsets[s]) { delete b; return APD_ERR_INVALID_ARG; }
@@ -266,7 +267,7 @@ extern "C" int apd_batch_create(apd_context *ctx, const float *frames, const uin
             }
             d_src = d_tmp;
         }
-        hipError_t e = launch_pad(d_src, b->d_frames, b->d_seq_off, b->d_src_off, n_seq, padded_frames, dim, b->dpad, ctx->stream);
+        hipError_t e = launch_pad(d_src, b->d_frames, b->d_seq_off, b->d_src_off, n_seq, padded_frames, dim, b->dim, b->dpad, ctx->stream);
         if (d_tmp) { hipStreamSynchronize(ctx->stream); hipFree(d_tmp); }
         if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return fail(APD_ERR_HIP); }
     }

@@ -42,13 +42,21 @@ struct AlignLaunch {
     float tau;
 };
 
+// Frame dimensions with instantiated kernels.  A batch of another dimension <= 26 is zero-padded up to the next one when it
+// is made resident (zero components change neither (x - y)^2 sums nor norms and dot products, bit for bit).
+constexpr int kKernelDims[] = {8, 10, 13, 16, 20, 26};
+constexpr bool is_kernel_dim(uint32_t d) { for (int k : kKernelDims) if ((uint32_t)k == d) return true; return false; }
+constexpr uint32_t kernel_dim(uint32_t d) { for (int k : kKernelDims) if ((uint32_t)k >= d) return (uint32_t)k; return d; }
+// Cells per lane the register file holds: (C + 2) frames of ceil4(D + 1) floats plus ~50 registers of state.
+constexpr int max_cells_per_lane(uint32_t d) { return d <= 13 ? 9 : 5; }
+
 // geom_key = G * 100 + C of the systolic kernel, or 0 for the generic kernel (see pick_geometry_key)
 hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, std::string &err, int *status);
 int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen);
 // >= 20000: full-matrix kernel, 20000 + NW * 100 + CW, for `cols` columns (0 if none fits)
 int pick_full_key(uint32_t cols, uint32_t dim, int variant);   // >= 10000: wide kernel, 10000 + NW * 100 + C
 hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_off, const uint32_t *d_src_off, uint32_t n_seq,
-                      uint64_t n_frames_padded, uint32_t dim, uint32_t dpad, hipStream_t stream);
+                      uint64_t n_frames_padded, uint32_t src_dim, uint32_t dim, uint32_t dpad, hipStream_t stream);
 hipError_t launch_unpack(const float *d_gathered, float *d_out, const uint32_t *d_order, uint32_t n_seq, uint32_t world,
                          uint64_t slab_floats, hipStream_t stream);
 hipError_t launch_selftest(int *d_result, hipStream_t stream);
@@ -94,7 +102,8 @@ struct apd_context {
 
 struct apd_batch {
     apd_context *ctx = nullptr;
-    uint32_t n_seq = 0, dim = 0, dpad = 0;
+    uint32_t n_seq = 0, dim = 0, dpad = 0;   // dim: resident (kernel) frame dimension, >= src_dim
+    uint32_t src_dim = 0;                    // the caller's frame dimension
     uint64_t total_frames = 0;
     float *d_frames = nullptr;        // padded layout with sentinels (see dtw_generic.hip)
     uint32_t frames_bytes = 0;

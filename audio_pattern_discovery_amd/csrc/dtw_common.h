@@ -57,6 +57,10 @@ __device__ __forceinline__ int pair_w(const BandSpec &b, int n, int m)
 // `force_match` makes the node take the MATCH branch regardless: the systolic kernel sets it on the cells just
 // outside a DP's band, whose MATCH predecessor (the same band offset one row up) is +INF by induction, so the cell
 // evaluates to +INF at the price of one scalar mask OR instead of a vector select.
+// The node is predecessor + (penalty * d) with the product rounded on its own, as the reference computes it: an fma
+// here would move last bits and with them the exact ties the select rule is sensitive to (a DELETE/INSERT tie takes
+// MATCH even when MATCH is larger).  UNIFORM_PEN: `d` is the already weighted distance (all penalties 1.0 in the
+// systolic kernel, where 1.0 * d == d; weight_distances elsewhere).
 template <bool UNIFORM_PEN>
 __device__ __forceinline__ float select_node(float del_v, float ins_v, float m_v, float d, float del_pen, float ins_pen,
                                              float mat_pen, bool force_match = false)
@@ -67,7 +71,7 @@ __device__ __forceinline__ float select_node(float del_v, float ins_v, float m_v
         // m_v.  So base = (del_v == ins_v) ? m_v : min3(del_v, ins_v, m_v): 3 VALU ops, no scalar mask arithmetic.
         // (Identical to the branch chain for non-NaN inputs; NaN features are outside the supported domain.)
         const float lo = __builtin_fminf(__builtin_fminf(del_v, ins_v), m_v);
-        return __builtin_fmaf(mat_pen, d, ((del_v == ins_v) | force_match) ? m_v : lo);
+        return __fadd_rn(((del_v == ins_v) | force_match) ? m_v : lo, d);
     }
     const bool pick_d = (del_v < m_v) & (del_v < ins_v) & !force_match;
     const bool pick_i = (ins_v < m_v) & (ins_v < del_v) & !force_match;
@@ -75,7 +79,15 @@ __device__ __forceinline__ float select_node(float del_v, float ins_v, float m_v
     base = pick_d ? del_v : base;
     float pen = pick_i ? ins_pen : mat_pen;
     pen = pick_d ? del_pen : pen;
-    return __builtin_fmaf(pen, d, base);
+    return __fadd_rn(base, __fmul_rn(pen, d));
+}
+
+// Uniform penalties (wide / full-matrix kernels): the distances of a row are weighted once, ahead of the DP rows.
+template <int C>
+__device__ __forceinline__ void weight_distances(float (&d)[C], float pen)
+{
+#pragma unroll
+    for (int c = 0; c < C; ++c) d[c] = __fmul_rn(d[c], pen);
 }
 
 // One unordered pair (a < b) of a tile.  Frames of sequence s live at d_frames[(seq_off[s] + t) * dpad], t in
@@ -126,6 +138,8 @@ bool launch_systolic(const AlignLaunch &L, int g, int c, bool uniform_pen, hipSt
 extern template bool launch_systolic<8>(const AlignLaunch &, int, int, bool, hipStream_t);
 extern template bool launch_systolic<10>(const AlignLaunch &, int, int, bool, hipStream_t);
 extern template bool launch_systolic<13>(const AlignLaunch &, int, int, bool, hipStream_t);
+extern template bool launch_systolic<16>(const AlignLaunch &, int, int, bool, hipStream_t);
+extern template bool launch_systolic<20>(const AlignLaunch &, int, int, bool, hipStream_t);
 extern template bool launch_systolic<26>(const AlignLaunch &, int, int, bool, hipStream_t);
 
 // Wide-band kernel (dtw_wide.h): NW waves per pair; returns false when (NW, C) is not instantiated.
@@ -134,6 +148,8 @@ bool launch_wide(const AlignLaunch &L, int nw, int c, hipStream_t stream, hipErr
 extern template bool launch_wide<8>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
 extern template bool launch_wide<10>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
 extern template bool launch_wide<13>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
+extern template bool launch_wide<16>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
+extern template bool launch_wide<20>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
 extern template bool launch_wide<26>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
 
 // Full-matrix kernel (dtw_full.h): column strips, one DP for both ordered pairs.
@@ -142,6 +158,8 @@ bool launch_full(const AlignLaunch &L, int nw, int cw, hipStream_t stream, hipEr
 extern template bool launch_full<8>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
 extern template bool launch_full<10>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
 extern template bool launch_full<13>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
+extern template bool launch_full<16>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
+extern template bool launch_full<20>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
 extern template bool launch_full<26>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
 
 }  // namespace apd

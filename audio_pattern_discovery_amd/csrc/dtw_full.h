@@ -12,7 +12,7 @@
 //                    macro-step (DPP wave_shr, or the LDS mailbox across a wave seam);
 //   INSERT (i-1, j): the lane's own previous row;
 //   MATCH (i-1, j-1): the lane's own previous row, or what it received as DELETE input one macro-step earlier.
-// One cross-lane move per macro-step, one workgroup barrier per macro-step when NW > 1, no frame traffic besides the
+// One cross-lane move per macro-step, one workgroup barrier per macro-step when NW > 1 (the seam mailbox is double-buffered), no frame traffic besides the
 // row frame (LDS ring, as in dtw_systolic.h).  Rows n and columns m are not swept (alignments.rs:120).
 #pragma once
 #include "dtw_systolic.h"
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(64 * NW) void dtw_full_matrix(const AlignLaunch L)
     constexpr uint32_t FB = DP * 4u;
     extern __shared__ float lds[];
     float *const xring = lds;                                     // [R][DP]
-    float *const mb_left = xring + R * DP;                        // [NW + 1]
+    float *const mb_left = xring + R * DP;                        // [2][NW + 1], double-buffered by macro-step parity
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, gl = threadIdx.x;
     const uint32_t tile = blockIdx.x / kSlotsPerTile, slot = blockIdx.x % kSlotsPerTile;
     const PairInfo P = decode_pair(L, tile, slot);                // one pair per workgroup: everything below is uniform
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64 * NW) void dtw_full_matrix(const AlignLaunch L)
     };
     for (int e = gl; e < G * DP; e += G)                          // rows <= 0: sentinels
         xring[((-(e / DP)) & (R - 1)) * DP + (e % DP)] = HYBRID ? ((e % DP) == D ? APD_INF : 0.0f) : -APD_INF;
-    if (gl <= NW) mb_left[gl] = APD_INF;                          // mb_left[0] stays +INF: column 0 does not exist
+    if (gl < 2 * (NW + 1)) mb_left[gl] = APD_INF;                 // entry 0 of either buffer stays +INF: column 0 does not exist
     {
         apd_f32x4 regs[NFILL];
         fill_load(1, regs);
@@ -132,9 +132,12 @@ __global__ __launch_bounds__(64 * NW) void dtw_full_matrix(const AlignLaunch L)
 #pragma unroll
                 for (int c = 0; c < CW; ++c) d[c] = frame_dist<D, DN>(xs, yf[c]);
             }
+            weight_distances<CW>(d, pen);
             read_row(xs, tau + 1 - gl);                           // the row frame is dead: fetch the next one under the DP row
             // DELETE input of the first column: last cell of the lane below (row i), across a wave seam from the mailbox
-            const float seam = (NW > 1) ? mb_left[wv] : APD_INF;
+            // (written one macro-step ago into the other buffer: a wave that runs ahead inside this barrier interval
+            // must not overwrite what a slower wave has yet to read)
+            const float seam = (NW > 1) ? mb_left[((q + 1) & 1) * (NW + 1) + wv] : APD_INF;
             const float left_in = from_lower_lane(last, seam);
             float left = left_in, mdiag = diag;
 #pragma unroll
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(64 * NW) void dtw_full_matrix(const AlignLaunch L)
             }
             if (q == U - 1) fill_store(tau0 + U + 1, fill_regs);  // rows of the next block, visible after this step's barrier
             if (NW > 1) {
-                if (lane == 63) mb_left[wv + 1] = last;
+                if (lane == 63) mb_left[(q & 1) * (NW + 1) + wv + 1] = last;
                 __syncthreads();
             }
         }
@@ -169,7 +172,7 @@ template <int D, int CW, int NW>
 static hipError_t launch_full_cn(const AlignLaunch &L, hipStream_t stream)
 {
     constexpr int G = 64 * NW, DP = (D + 1 + 3) & ~3, R = (G <= 64) ? 128 : ((G <= 256) ? 512 : 1024);
-    const size_t lds_bytes = ((size_t)R * DP + (NW + 1) + 16) * sizeof(float);
+    const size_t lds_bytes = ((size_t)R * DP + 2 * (NW + 1) + 16) * sizeof(float);
     const dim3 grid(L.n_tiles * kSlotsPerTile), block(G);
     const bool hybrid = L.hybrid && D >= 10;
     const void *fn = hybrid ? reinterpret_cast<const void *>(dtw_full_matrix<D, CW, NW, true>) : reinterpret_cast<const void *>(dtw_full_matrix<D, CW, NW, false>);
@@ -186,7 +189,7 @@ static hipError_t launch_full_cn(const AlignLaunch &L, hipStream_t stream)
 template <int D>
 bool launch_full(const AlignLaunch &L, int nw, int cw, hipStream_t stream, hipError_t *err)
 {
-#define APD_FCASE(NN, CC) if constexpr (CC < 9 || D <= 16) { if (nw == NN && cw == CC) { *err = launch_full_cn<D, CC, NN>(L, stream); return true; } }
+#define APD_FCASE(NN, CC) if constexpr (CC <= max_cells_per_lane(D)) { if (nw == NN && cw == CC) { *err = launch_full_cn<D, CC, NN>(L, stream); return true; } }
     APD_FCASE(1, 3) APD_FCASE(1, 5) APD_FCASE(1, 9) APD_FCASE(2, 9) APD_FCASE(4, 5) APD_FCASE(4, 9) APD_FCASE(8, 5) APD_FCASE(8, 9)
 #undef APD_FCASE
     return false;

@@ -107,7 +107,8 @@ __global__ __launch_bounds__(64) void dtw_fused_generic(const AlignLaunch L, int
 // zero components and norm +INF (hybrid distances), sentinel E has +INF components (difference-form distances).
 // ------------------------------------------------------------------------------------------------
 __global__ void pad_frames_kernel(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ seq_off,
-                                  const uint32_t *__restrict__ src_off, uint32_t n_seq, uint64_t n_frames_padded, uint32_t dim, uint32_t dpad)
+                                  const uint32_t *__restrict__ src_off, uint32_t n_seq, uint64_t n_frames_padded, uint32_t src_dim,
+                                  uint32_t dim, uint32_t dpad)
 {
     const uint64_t total = n_frames_padded * dpad;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
@@ -120,9 +121,9 @@ __global__ void pad_frames_kernel(const float *__restrict__ src, float *__restri
         if (sent_e) v = (k <= dim) ? APD_INF : 0.0f;
         else if (sent_h) v = (k == dim) ? APD_INF : 0.0f;
         else {
-            const float *fr = src + (uint64_t)(src_off[lo] + (f - seq_off[lo])) * dim;
-            if (k < dim) v = fr[k];
-            else if (k == dim) { double acc = 0.0; for (uint32_t t = 0; t < dim; ++t) acc += (double)fr[t] * (double)fr[t]; v = (float)acc; }
+            const float *fr = src + (uint64_t)(src_off[lo] + (f - seq_off[lo])) * src_dim;
+            if (k < src_dim) v = fr[k];                       // components src_dim .. dim - 1 stay zero
+            else if (k == dim) { double acc = 0.0; for (uint32_t t = 0; t < src_dim; ++t) acc += (double)fr[t] * (double)fr[t]; v = (float)acc; }
         }
         dst[e] = v;
     }
@@ -169,13 +170,13 @@ hipError_t launch_selftest(int *d_result, hipStream_t stream)
 }
 
 hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_off, const uint32_t *d_src_off, uint32_t n_seq,
-                      uint64_t n_frames_padded, uint32_t dim, uint32_t dpad, hipStream_t stream)
+                      uint64_t n_frames_padded, uint32_t src_dim, uint32_t dim, uint32_t dpad, hipStream_t stream)
 {
     if (n_frames_padded == 0) return hipSuccess;
     const uint64_t total = n_frames_padded * dpad;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 16384);
     hipLaunchKernelGGL(pad_frames_kernel, dim3(blocks), dim3(256), 0, stream, d_src, d_dst, d_seq_off, d_src_off, n_seq, n_frames_padded,
-                       dim, dpad);
+                       src_dim, dim, dpad);
     return hipGetLastError();
 }
 
@@ -199,7 +200,7 @@ struct Geometry { int g, c; };
 int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen)
 {
     if (variant == 1) return 0;                                        // forced generic kernel
-    if (!(dim == 8 || dim == 10 || dim == 13 || dim == 26)) return 0;  // instantiated frame dimensions
+    if (!is_kernel_dim(dim)) return 0;                                 // instantiated frame dimensions
     if (variant >= 10000) {                                            // forced wide geometry (tuning)
         const int nw = (variant - 10000) / 100, c = variant % 100;
         return (uniform_pen && (uint32_t)(64 * nw * c) >= need) ? variant : 0;
@@ -212,7 +213,7 @@ int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen
     Geometry best{0, 0};
     double best_util = 0.0;
     for (const Geometry &q : all) {
-        if ((uint32_t)(q.g * q.c) < need || (q.c == 9 && dim > 16)) continue;
+        if ((uint32_t)(q.g * q.c) < need || q.c > max_cells_per_lane(dim)) continue;
         const double util = (double)need / (double)(q.g * q.c) - 0.004 * (9 - q.c);   // larger C: fewer exchanges per cell
         if (util > best_util) { best_util = util; best = q; }
     }
@@ -221,7 +222,7 @@ int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen
     if (uniform_pen) {
         static const Geometry wide[] = {{2, 5}, {2, 9}, {4, 5}, {4, 9}, {8, 5}, {8, 9}};   // (NW, C), ascending capacity
         for (const Geometry &q : wide)
-            if ((uint32_t)(64 * q.g * q.c) >= need && !(q.c == 9 && dim > 16)) return 10000 + q.g * 100 + q.c;
+            if ((uint32_t)(64 * q.g * q.c) >= need && q.c <= max_cells_per_lane(dim)) return 10000 + q.g * 100 + q.c;
     }
     return 0;
 }
@@ -229,14 +230,14 @@ int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen
 int pick_full_key(uint32_t cols, uint32_t dim, int variant)
 {
     if (variant != 0 && variant < 20000) return 0;                     // another kernel was requested
-    if (!(dim == 8 || dim == 10 || dim == 13 || dim == 26)) return 0;
+    if (!is_kernel_dim(dim)) return 0;
     if (variant >= 20000) {
         const int nw = (variant - 20000) / 100, cw = variant % 100;
         return ((uint32_t)(64 * nw * cw) >= cols) ? variant : 0;
     }
     static const Geometry full[] = {{1, 3}, {1, 5}, {1, 9}, {2, 9}, {4, 5}, {4, 9}, {8, 5}, {8, 9}};   // (NW, CW), ascending capacity
     for (const Geometry &q : full)
-        if ((uint32_t)(64 * q.g * q.c) >= cols && !(q.c == 9 && dim > 16)) return 20000 + q.g * 100 + q.c;
+        if ((uint32_t)(64 * q.g * q.c) >= cols && q.c <= max_cells_per_lane(dim)) return 20000 + q.g * 100 + q.c;
     return 0;
 }
 
@@ -245,7 +246,7 @@ hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, 
     *status = APD_OK;
     if (L.n_tiles == 0) return hipSuccess;
     const BandSpec &b = L.band;
-    const bool uniform = (b.ins == b.del) && (b.del == b.mat);
+    const bool unit = (b.ins == 1.0f) && (b.del == 1.0f) && (b.mat == 1.0f);   // the systolic kernel's UNIFORM_PEN path: no weighting at all
     bool done = false;
     AlignLaunch LL = L;
     if (LL.dim < 10) LL.hybrid = 0;            // the norm expansion saves D - 4 vector ops per cell: not worth its branch below D = 10
@@ -256,6 +257,8 @@ hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, 
             case 8: done = launch_full<8>(LL, nw, cw, stream, &fe); break;
             case 10: done = launch_full<10>(LL, nw, cw, stream, &fe); break;
             case 13: done = launch_full<13>(LL, nw, cw, stream, &fe); break;
+            case 16: done = launch_full<16>(LL, nw, cw, stream, &fe); break;
+            case 20: done = launch_full<20>(LL, nw, cw, stream, &fe); break;
             case 26: done = launch_full<26>(LL, nw, cw, stream, &fe); break;
             default: break;
         }
@@ -267,6 +270,8 @@ hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, 
             case 8: done = launch_wide<8>(LL, nw, c, stream, &we); break;
             case 10: done = launch_wide<10>(LL, nw, c, stream, &we); break;
             case 13: done = launch_wide<13>(LL, nw, c, stream, &we); break;
+            case 16: done = launch_wide<16>(LL, nw, c, stream, &we); break;
+            case 20: done = launch_wide<20>(LL, nw, c, stream, &we); break;
             case 26: done = launch_wide<26>(LL, nw, c, stream, &we); break;
             default: break;
         }
@@ -274,10 +279,12 @@ hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, 
     } else if (geom_key != 0) {
         const int g = geom_key / 100, c = geom_key % 100;
         switch (L.dim) {
-            case 8: done = launch_systolic<8>(LL, g, c, uniform, stream); break;
-            case 10: done = launch_systolic<10>(LL, g, c, uniform, stream); break;
-            case 13: done = launch_systolic<13>(LL, g, c, uniform, stream); break;
-            case 26: done = launch_systolic<26>(LL, g, c, uniform, stream); break;
+            case 8: done = launch_systolic<8>(LL, g, c, unit, stream); break;
+            case 10: done = launch_systolic<10>(LL, g, c, unit, stream); break;
+            case 13: done = launch_systolic<13>(LL, g, c, unit, stream); break;
+            case 16: done = launch_systolic<16>(LL, g, c, unit, stream); break;
+            case 20: done = launch_systolic<20>(LL, g, c, unit, stream); break;
+            case 26: done = launch_systolic<26>(LL, g, c, unit, stream); break;
             default: break;
         }
     }

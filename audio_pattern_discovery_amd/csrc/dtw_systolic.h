@@ -356,8 +356,8 @@ static void launch_systolic_cg(const AlignLaunch &L, bool uniform, hipStream_t s
 template <int D>
 bool launch_systolic(const AlignLaunch &L, int g, int c, bool uniform, hipStream_t stream)
 {
-    // C = 9 keeps 10 column frames per lane in registers: only for D <= 16 (D = 26 would spill)
-#define APD_CASE(GG, CC) if constexpr (CC < 9 || D <= 16) { if (g == GG && c == CC) { launch_systolic_cg<D, CC, GG>(L, uniform, stream); return true; } }
+    // C = 9 keeps 10 column frames per lane in registers: only for D <= 13 (max_cells_per_lane)
+#define APD_CASE(GG, CC) if constexpr (CC <= max_cells_per_lane(D)) { if (g == GG && c == CC) { launch_systolic_cg<D, CC, GG>(L, uniform, stream); return true; } }
     APD_CASE(8, 9)
     APD_CASE(16, 2) APD_CASE(16, 3) APD_CASE(16, 5) APD_CASE(16, 9)
     APD_CASE(64, 3) APD_CASE(64, 5) APD_CASE(64, 9)

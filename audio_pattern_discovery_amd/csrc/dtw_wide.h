@@ -167,6 +167,7 @@ __global__ __launch_bounds__(64 * NW) void dtw_fused_wide(const AlignLaunch L)
 #pragma unroll
                     for (int c = 0; c < C; ++c) d[c] = frame_dist<D, DN>(xs, yf[(r + c) % S]);
                 }
+                weight_distances<C>(d, pen);
                 // first cell, then the seam exchange of the "up" neighbour
                 float left1 = from_lower_lane(prev1[C - 1], lf1);
                 float left2 = from_lower_lane(prev2[C - 1], lf2);
@@ -241,7 +242,7 @@ static hipError_t launch_wide_cn(const AlignLaunch &L, hipStream_t stream)
 template <int D>
 bool launch_wide(const AlignLaunch &L, int nw, int c, hipStream_t stream, hipError_t *err)
 {
-#define APD_WCASE(NN, CC) if constexpr (CC < 9 || D <= 16) { if (nw == NN && c == CC) { *err = launch_wide_cn<D, CC, NN>(L, stream); return true; } }
+#define APD_WCASE(NN, CC) if constexpr (CC <= max_cells_per_lane(D)) { if (nw == NN && c == CC) { *err = launch_wide_cn<D, CC, NN>(L, stream); return true; } }
     APD_WCASE(2, 5) APD_WCASE(2, 9) APD_WCASE(4, 5) APD_WCASE(4, 9) APD_WCASE(8, 5) APD_WCASE(8, 9)
 #undef APD_WCASE
     return false;

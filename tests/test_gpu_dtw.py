@@ -93,6 +93,19 @@ def test_random_batches_match_oracle(ctx, oracle, variant, dim, pct, n_seq, leng
     assert np.all(np.diag(got) == 0.0)                # alignments.rs:51
 
 
+@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("dim", [2, 7, 9, 11, 12, 14, 16, 17, 20, 21, 25, 27, 40])
+def test_any_frame_dimension(ctx, oracle, variant, dim):
+    """Dimensions without their own instantiation are zero-padded to the next one when made resident (bit-neutral for
+    the distances); beyond 26 the generic kernel runs.  Banded with ties, and full DTW on ragged lengths."""
+    frames, offsets = synth.make_sequences(20, 70, dim, seed=4000 + dim, integer=(dim % 2 == 0), jitter=6)
+    want = oracle.align_all(frames, offsets, 0.1, 0.8, 1.2, 1.0, workers=8)
+    assert_parity(gpu_align_all(ctx, frames, offsets, dim, 0.1, 0.8, 1.2, 1.0, variant=variant), want)
+    frames, offsets = synth.make_sequences(18, 110, dim, seed=5000 + dim, jitter=50)
+    want = oracle.align_all(frames, offsets, 1.0, workers=8)
+    assert_parity(gpu_align_all(ctx, frames, offsets, dim, 1.0, variant=variant), want)
+
+
 def test_matrix_is_directed_when_band_binds(ctx, oracle):
     # the band j-i in [-w, w-1] is asymmetric, so d(i,j) != d(j,i) in general: both triangles are computed
     frames, offsets = synth.make_sequences(16, 150, 13, seed=99, jitter=12)
@@ -318,3 +331,22 @@ def test_full_matrix_kernel(ctx, oracle, variant, distance):
     ctx.set_distance_mode("hybrid")
     assert_parity(got, want)
     assert got[5, 8] == 0.0 and got[8, 5] == 0.0
+
+
+@pytest.mark.parametrize("dim,lo,hi,pct", [(10, 150, 900, 1.0), (13, 500, 2400, 1.0), (13, 300, 1200, 0.5), (26, 200, 700, 1.0)])
+def test_multi_wave_kernels_are_deterministic(ctx, oracle, dim, lo, hi, pct):
+    """Ragged corpora on the multi-wave kernels (full-matrix NW up to 8; band-form wide kernel for pct 0.5): the waves of
+    a workgroup hand DP values across their seams through LDS mailboxes, so besides parity the result must be bitwise
+    the same run after run (a mailbox overwritten before a slower wave has read it shows up here)."""
+    from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
+    from audio_pattern_discovery_amd.discovery import Discovery
+    n = 40
+    frames, offsets = synth.make_sequences(n, (lo + hi) // 2, dim, seed=31 * dim + hi, jitter=(hi - lo) // 2)
+    seqs = [NDSequence(s) for s in synth.split(frames, offsets)]
+    cfg = Discovery(warping_band_percentage=pct)
+    runs = []
+    for _ in range(4):
+        runs.append(AlignmentWorkers.new(seqs, ctx).align_all(cfg).reshape(n, n).copy())
+    for r in runs[1:]:
+        assert np.array_equal(runs[0], r)
+    assert_parity(runs[0], oracle.align_all(frames, offsets, pct, workers=16))
