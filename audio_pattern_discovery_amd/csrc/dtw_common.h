@@ -2,6 +2,10 @@
 #pragma once
 #include "apd_internal.h"
 
+// No implicit fusing of a*b+c anywhere in the alignment kernels (the Makefile passes -ffp-contract=off as well): the fma chains
+// are written out with __builtin_fmaf, everything else rounds operation by operation as the reference does.
+#pragma clang fp contract(off)
+
 namespace apd {
 
 #define APD_INF __builtin_inff()
@@ -71,7 +75,7 @@ __device__ __forceinline__ float select_node(float del_v, float ins_v, float m_v
         // m_v.  So base = (del_v == ins_v) ? m_v : min3(del_v, ins_v, m_v): 3 VALU ops, no scalar mask arithmetic.
         // (Identical to the branch chain for non-NaN inputs; NaN features are outside the supported domain.)
         const float lo = __builtin_fminf(__builtin_fminf(del_v, ins_v), m_v);
-        return __fadd_rn(((del_v == ins_v) | force_match) ? m_v : lo, d);
+        return ((del_v == ins_v) | force_match ? m_v : lo) + d;
     }
     const bool pick_d = (del_v < m_v) & (del_v < ins_v) & !force_match;
     const bool pick_i = (ins_v < m_v) & (ins_v < del_v) & !force_match;
@@ -79,7 +83,8 @@ __device__ __forceinline__ float select_node(float del_v, float ins_v, float m_v
     base = pick_d ? del_v : base;
     float pen = pick_i ? ins_pen : mat_pen;
     pen = pick_d ? del_pen : pen;
-    return __fadd_rn(base, __fmul_rn(pen, d));
+    const float weighted = pen * d;                               // rounded on its own (alignments.rs:154-158)
+    return base + weighted;
 }
 
 // Uniform penalties (wide / full-matrix kernels): the distances of a row are weighted once, ahead of the DP rows.
@@ -87,7 +92,7 @@ template <int C>
 __device__ __forceinline__ void weight_distances(float (&d)[C], float pen)
 {
 #pragma unroll
-    for (int c = 0; c < C; ++c) d[c] = __fmul_rn(d[c], pen);
+    for (int c = 0; c < C; ++c) d[c] = d[c] * pen;
 }
 
 // One unordered pair (a < b) of a tile.  Frames of sequence s live at d_frames[(seq_off[s] + t) * dpad], t in

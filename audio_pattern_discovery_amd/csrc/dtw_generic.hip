@@ -64,17 +64,19 @@ __global__ __launch_bounds__(64) void dtw_fused_generic(const AlignLaunch L, int
         for (int c = 0; c < C; ++c) {
             const int j = jb + c, u = u0 + c;
             const float4 *yb = reinterpret_cast<const float4 *>(P.B + (uint64_t)(min(max(j, 1), m) - 1) * L.dpad);
+            // numerics.rs:114-120 operation for operation (difference, square, sum each rounded; correctly rounded sqrt):
+            // this kernel serves every penalty setting, and with unequal penalties near-ties must resolve as on the CPU
             float acc = 0.0f;
             for (int q = 0; q < dp4; ++q) {                  // slots >= dim hold the squared norm / padding: skipped
                 const float4 xv = xa[q], yv = yb[q];
                 const int k0 = 4 * q;
-                float t = xv.x - yv.x;
-                acc = (q == 0) ? t * t : ((k0 < dim) ? __builtin_fmaf(t, t, acc) : acc);
-                t = xv.y - yv.y; acc = (k0 + 1 < dim) ? __builtin_fmaf(t, t, acc) : acc;
-                t = xv.z - yv.z; acc = (k0 + 2 < dim) ? __builtin_fmaf(t, t, acc) : acc;
-                t = xv.w - yv.w; acc = (k0 + 3 < dim) ? __builtin_fmaf(t, t, acc) : acc;
+                float t = xv.x - yv.x, sq = t * t;
+                acc = (k0 < dim) ? acc + sq : acc;
+                t = xv.y - yv.y; sq = t * t; acc = (k0 + 1 < dim) ? acc + sq : acc;
+                t = xv.z - yv.z; sq = t * t; acc = (k0 + 2 < dim) ? acc + sq : acc;
+                t = xv.w - yv.w; sq = t * t; acc = (k0 + 3 < dim) ? acc + sq : acc;
             }
-            const float d = __builtin_amdgcn_sqrtf(acc);
+            const float d = __builtin_sqrtf(acc);
             const float m1 = nxt1, m2 = nxt2;
             float up1, up2;
             if (c < C - 1) { up1 = p1[(c + 1) * 64 + lane]; up2 = p2[(c + 1) * 64 + lane]; }

@@ -71,6 +71,24 @@ __device__ __forceinline__ float frame_dist(const float (&x)[DN], const float (&
     return __builtin_amdgcn_sqrtf(acc);
 }
 
+// numerics.rs:114-120 operation for operation: every difference, square and partial sum rounded on its own, then the
+// correctly rounded square root -- the bits the CPU code produces.  Used with non-unit penalties, where the node update
+// adds a penalty that depends on WHICH predecessor won: a near-tie resolved the other way moves the score by percents,
+// so the comparison inputs must be the reference's to the last bit.
+template <int D, int DN>
+__device__ __forceinline__ float frame_dist_strict(const float (&x)[DN], const float (&y)[DN])
+{
+    float t = x[0] - y[0];
+    float acc = t * t;                                            // 0.0 + t*t == t*t
+#pragma unroll
+    for (int k = 1; k < D; ++k) {
+        t = x[k] - y[k];
+        const float sq = t * t;
+        acc = acc + sq;
+    }
+    return __builtin_sqrtf(acc);                                  // correctly rounded (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt)
+}
+
 // Squared distance by norm expansion: x[D], y[D] hold the squared norms.  13 fma + 2 instead of 26 (D = 13).
 template <int D>
 __device__ __forceinline__ float frame_sq_expanded(const float (&x)[D + 1], const float (&y)[D + 1], float &s_out)
@@ -277,7 +295,9 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                     read_row(xs[0], tau + 1 - gl);                // the row frame is dead now: fetch the next one under the DP rows
                 } else {
 #pragma unroll
-                    for (int c = 0; c < C; ++c) d[c] = (PIPE && c < C - 1) ? dn[c] : frame_dist<D, DN>(xs[xa], yf[(r + c) % S]);
+                    for (int c = 0; c < C; ++c)
+                        d[c] = !UNIFORM_PEN ? frame_dist_strict<D, DN>(xs[xa], yf[(r + c) % S])
+                                            : ((PIPE && c < C - 1) ? dn[c] : frame_dist<D, DN>(xs[xa], yf[(r + c) % S]));
                     if (PIPE) {
 #pragma unroll
                         for (int c = 0; c < C - 1; ++c) dn[c] = frame_dist<D, DN>(xs[xb], yf[(r + 1 + c) % S]);
@@ -338,26 +358,23 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
 }
 
 template <int D, int C, int G>
-static void launch_systolic_cg(const AlignLaunch &L, bool uniform, hipStream_t stream)
+static void launch_systolic_cg(const AlignLaunch &L, bool unit, hipStream_t stream)
 {
     constexpr int PPW = 64 / G;
     constexpr int WPT = kSlotsPerTile / (4 * PPW);
     const uint32_t tiles8 = (L.n_tiles + 7u) / 8u * 8u;
     const dim3 grid(tiles8 * WPT), block(256);
-    if (L.hybrid) {
-        if (uniform) hipLaunchKernelGGL((dtw_fused_systolic<D, C, G, true, true>), grid, block, 0, stream, L);
-        else hipLaunchKernelGGL((dtw_fused_systolic<D, C, G, false, true>), grid, block, 0, stream, L);
-    } else {
-        if (uniform) hipLaunchKernelGGL((dtw_fused_systolic<D, C, G, true, false>), grid, block, 0, stream, L);
-        else hipLaunchKernelGGL((dtw_fused_systolic<D, C, G, false, false>), grid, block, 0, stream, L);
-    }
+    // unit penalties: the fast select, either distance form; anything else: literal select on strict (bit-faithful) distances
+    if (!unit) hipLaunchKernelGGL((dtw_fused_systolic<D, C, G, false, false>), grid, block, 0, stream, L);
+    else if (L.hybrid) hipLaunchKernelGGL((dtw_fused_systolic<D, C, G, true, true>), grid, block, 0, stream, L);
+    else hipLaunchKernelGGL((dtw_fused_systolic<D, C, G, true, false>), grid, block, 0, stream, L);
 }
 
 template <int D>
-bool launch_systolic(const AlignLaunch &L, int g, int c, bool uniform, hipStream_t stream)
+bool launch_systolic(const AlignLaunch &L, int g, int c, bool unit, hipStream_t stream)
 {
     // C = 9 keeps 10 column frames per lane in registers: only for D <= 13 (max_cells_per_lane)
-#define APD_CASE(GG, CC) if constexpr (CC <= max_cells_per_lane(D)) { if (g == GG && c == CC) { launch_systolic_cg<D, CC, GG>(L, uniform, stream); return true; } }
+#define APD_CASE(GG, CC) if constexpr (CC <= max_cells_per_lane(D)) { if (g == GG && c == CC) { launch_systolic_cg<D, CC, GG>(L, unit, stream); return true; } }
     APD_CASE(8, 9)
     APD_CASE(16, 2) APD_CASE(16, 3) APD_CASE(16, 5) APD_CASE(16, 9)
     APD_CASE(64, 3) APD_CASE(64, 5) APD_CASE(64, 9)

@@ -1,0 +1,71 @@
+"""Randomised parity sweep of the alignment path (C ABI -> HIP kernels) against the CPU oracle.
+
+Every case draws frame dimension, corpus size, lengths (ragged), band percentage, penalties, integer or real
+features and the distance form.  Unit penalties: 1e-4 relative (BASELINE.json north_star).  Unequal penalties: the
+reference's node update is DISCONTINUOUS in its inputs (the penalty added depends on which predecessor won a
+strict comparison), so the kernels compute those cases with the reference's arithmetic operation for operation
+and the test asks for the same bits.  tools/debug/fuzz.py is the open-ended version of this sweep.
+"""
+import numpy as np
+import pytest
+
+from audio_pattern_discovery_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(seed, count):
+    rng = np.random.default_rng(seed)
+    for _ in range(count):
+        dim = int(rng.choice([1, 2, 3, 5, 8, 9, 10, 12, 13, 15, 16, 19, 20, 23, 26, 27, 33]))
+        n_seq = int(rng.integers(2, 40))
+        length = int(rng.choice([3, 8, 20, 60, 150, 400, 900]))
+        jitter = int(rng.integers(0, max(length - 1, 1)))
+        pct = float(rng.choice([0.0, 0.01, 0.0625, 0.1, 0.25, 0.5, 0.9, 1.0, 1.5]))
+        integer = bool(rng.random() < 0.4)
+        pk = rng.random()
+        if pk < 0.4:
+            pens = (1.0, 1.0, 1.0)
+        elif pk < 0.55:
+            pens = (0.7, 0.7, 0.7)
+        else:
+            pens = tuple(float(v) for v in rng.choice([0.25, 0.5, 0.8, 1.0, 1.2, 2.0], 3))
+        mode = "hybrid" if rng.random() < 0.6 else "exact"
+        if length >= 400:
+            n_seq = min(n_seq, 12)
+        yield dict(dim=dim, n_seq=n_seq, length=length, jitter=jitter, pct=pct, integer=integer, pens=pens, mode=mode,
+                   seed=int(rng.integers(1 << 30)), copies=float(rng.choice([0.0, 0.25, 0.6])))
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_configurations_match_the_oracle(apd, oracle, seed):
+    from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
+    from audio_pattern_discovery_amd.discovery import Discovery
+    ctx = apd.Context(0)
+    failures = []
+    try:
+        for k, c in enumerate(_cases(seed, 60)):
+            frames, offsets = synth.make_sequences(c["n_seq"], c["length"], c["dim"], seed=c["seed"], integer=c["integer"],
+                                                   jitter=c["jitter"], copies=c["copies"])
+            ins, dele, mat = c["pens"]
+            want = oracle.align_all(frames, offsets, c["pct"], ins, dele, mat, workers=8)
+            ctx.set_distance_mode(c["mode"])
+            seqs = [NDSequence(s) for s in synth.split(frames, offsets)]
+            got = AlignmentWorkers.new(seqs, ctx).align_all(
+                Discovery(warping_band_percentage=c["pct"], insertion_penalty=ins, deletion_penalty=dele,
+                          match_penalty=mat)).reshape(c["n_seq"], c["n_seq"])
+            if not (ins == dele == mat):                       # strict arithmetic: the reference's bits
+                if not np.array_equal(got, want):
+                    failures.append((k, c, "not bit-identical"))
+                continue
+            fin = np.isfinite(want)
+            ok = np.array_equal(fin, np.isfinite(got)) and np.array_equal(np.isposinf(want), np.isposinf(got))
+            zero = fin & (want == 0)
+            ok = ok and bool(np.all(got[zero] == 0))
+            nz = fin & ~zero
+            rel = float((np.abs(got[nz] - want[nz]) / np.abs(want[nz])).max()) if (ok and nz.any()) else 0.0
+            if not ok or rel > 1e-4:
+                failures.append((k, c, rel))
+    finally:
+        ctx.close()
+    assert not failures, failures[:3]

@@ -1,0 +1,75 @@
+"""Randomised parity sweep of the alignment path against the CPU oracle (run on the GPU box).
+usage: python tools/debug/fuzz.py [n_cases] [seed]"""
+import sys, time, numpy as np
+sys.path.insert(0, ".")
+import torch  # noqa: F401  (loads the HIP runtime first)
+from audio_pattern_discovery_amd import synth, _lib
+from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
+from audio_pattern_discovery_amd.discovery import Discovery
+from oracle import binding as oracle
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+ctx = _lib.Context(0)
+worst, fails = 0.0, 0
+t0 = time.time()
+for case in range(n_cases):
+    dim = int(rng.choice([1, 2, 3, 5, 8, 9, 10, 12, 13, 15, 16, 19, 20, 23, 26, 27, 33]))
+    n_seq = int(rng.integers(2, 50))
+    length = int(rng.choice([3, 8, 20, 60, 150, 400, 900]))
+    jitter = int(rng.integers(0, max(length - 1, 1)))
+    pct = float(rng.choice([0.0, 0.01, 0.0625, 0.1, 0.25, 0.5, 0.9, 1.0, 1.5]))
+    integer = bool(rng.random() < 0.4)
+    pk = rng.random()
+    pens = (1.0, 1.0, 1.0) if pk < 0.5 else ((0.7, 0.7, 0.7) if pk < 0.65 else tuple(float(v) for v in rng.choice([0.25, 0.5, 0.8, 1.0, 1.2, 2.0], 3)))
+    mode = "hybrid" if rng.random() < 0.6 else "exact"
+    if length >= 400:
+        n_seq = min(n_seq, 14)
+    frames, offsets = synth.make_sequences(n_seq, length, dim, seed=int(rng.integers(1 << 30)), integer=integer, jitter=jitter,
+                                           copies=float(rng.choice([0.0, 0.25, 0.6])))
+    want = oracle.align_all(frames, offsets, pct, *pens, workers=16)
+    ctx.set_distance_mode(mode)
+    seqs = [NDSequence(s) for s in synth.split(frames, offsets)]
+    got = AlignmentWorkers.new(seqs, ctx).align_all(Discovery(warping_band_percentage=pct, insertion_penalty=pens[0], deletion_penalty=pens[1],
+                                                              match_penalty=pens[2])).reshape(n_seq, n_seq)
+    fin = np.isfinite(want)
+    ok = np.array_equal(fin, np.isfinite(got)) and np.array_equal(np.isposinf(want), np.isposinf(got))
+    rel = 0.0
+    if ok:
+        zero = fin & (want == 0)
+        ok = bool(np.all(got[zero] == 0))
+        nz = fin & ~zero
+        if nz.any():
+            rel = float((np.abs(got[nz] - want[nz]) / np.abs(want[nz])).max())
+            ok = ok and rel <= 1e-4
+    worst = max(worst, rel)
+    if pens != (1.0, 1.0, 1.0):
+        nonunit = globals().setdefault("nonunit", [0, 0])
+        nonunit[0] += 1
+        nonunit[1] += int(np.array_equal(got, want))
+    if not ok:
+        extra = {}
+        for name, var, md in (("generic", 1, mode), ("fast_exact", 0, "exact"), ("fast_hybrid", 0, "hybrid")):
+            ctx.set_variant(var); ctx.set_distance_mode(md)
+            g2 = AlignmentWorkers.new(seqs, ctx).align_all(Discovery(warping_band_percentage=pct, insertion_penalty=pens[0], deletion_penalty=pens[1],
+                                                                     match_penalty=pens[2])).reshape(n_seq, n_seq)
+            m = np.isfinite(want) & (want != 0)
+            extra[name] = float((np.abs(g2[m] - want[m]) / np.abs(want[m])).max()) if m.any() else 0.0
+            bad = np.argwhere(m & (np.abs(g2 - want) > 1e-4 * np.abs(want)))
+            extra[name + "_nbad"] = len(bad)
+        ctx.set_variant(0)
+        lens = np.diff(offsets.astype(np.int64))
+        sq = synth.split(frames, offsets)
+        for a, b in bad[:3]:
+            band = oracle.warping_band(pct, max(lens[a], lens[b]))
+            print("    pair", a, b, "lens", lens[a], lens[b], "band", band, "gpu", g2[a, b], "want", want[a, b],
+                  "oracle_hashmap", oracle.dtw_pair(sq[a], sq[b], band, *pens, hashmap=True), "oracle_dense", oracle.dtw_pair(sq[a], sq[b], band, *pens),
+                  "gpu_T", g2[b, a], "want_T", want[b, a], "same_frames", bool(lens[a] == lens[b] and np.array_equal(sq[a], sq[b])))
+        print("   ", extra, "lens", lens.min(), lens.max(), flush=True)
+        fails += 1
+        print("FAIL case", case, dict(dim=dim, n_seq=n_seq, length=length, jitter=jitter, pct=pct, integer=integer, pens=pens, mode=mode), "rel", rel, flush=True)
+    if case % 20 == 19:
+        print("case", case + 1, "worst rel", worst, "fails", fails, "%.0fs" % (time.time() - t0), flush=True)
+print("done: cases", n_cases, "fails", fails, "worst rel", worst, "non-unit penalty cases / bit-exact:", globals().get("nonunit"))
+sys.exit(1 if fails else 0)
