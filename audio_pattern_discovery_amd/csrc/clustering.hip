@@ -271,13 +271,45 @@ __global__ __launch_bounds__(256) void upgma_update_kernel(UpgmaState st)
     const uint32_t *lx = st.pool + st.mstart[dir ? s : sp], *ly = st.pool + st.mstart[dir ? sp : s];
     const uint32_t cx = st.mcount[dir ? s : sp], cy = st.mcount[dir ? sp : s];
     float acc = 0.0f;
-    for (uint32_t a = 0; a < cx; ++a) {
-        const float *row = st.d + (uint64_t)lx[a] * st.n;
-        for (uint32_t b0 = 0; b0 < cy; b0 += 64) {
-            const uint32_t cnt = min(64u, cy - b0);
-            const float v = (lane < cnt) ? row[ly[b0 + lane]] : 0.0f;
-            for (uint32_t t = 0; t < cnt; ++t)
-                acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t));
+    const uint64_t total = (uint64_t)cx * cy;
+    if (total < (1ull << 32)) {
+        // the (x, y) pairs in linkage()'s order are one linear sequence e = a * cy + b: 64 at a time are gathered (lane = e & 63),
+        // kPre chunks ahead of the adds so that the gather latency hides behind them; a chunk is padded with +0.0, which the
+        // accumulator absorbs exactly, so every chunk is the same 64 unrolled readlane + add steps.
+        constexpr int kPre = 8;
+        const uint32_t tot = (uint32_t)total;
+        auto fetch = [&](uint32_t e0) __attribute__((always_inline)) -> float {
+            const uint32_t e = e0 + lane;
+            if (e0 >= tot || e >= tot) return 0.0f;
+            const uint32_t a = e / cy, b = e - a * cy;
+            return st.d[(uint64_t)lx[a] * st.n + ly[b]];
+        };
+        float buf[kPre];
+#pragma unroll
+        for (int k = 0; k < kPre; ++k) buf[k] = fetch((uint32_t)k * 64u);
+        for (uint64_t e0 = 0; e0 < total; e0 += 64ull * kPre) {
+#pragma unroll
+            for (int k = 0; k < kPre; ++k) {
+                const uint64_t ek = e0 + 64ull * k;
+                if (ek < total) {                                        // wave-uniform
+                    const float v = buf[k];
+                    const uint64_t nx = ek + 64ull * kPre;
+                    buf[k] = (nx < total) ? fetch((uint32_t)nx) : 0.0f;
+#pragma unroll
+                    for (int t = 0; t < 64; ++t)
+                        acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t));
+                }
+            }
+        }
+    } else {
+        for (uint32_t a = 0; a < cx; ++a) {
+            const float *row = st.d + (uint64_t)lx[a] * st.n;
+            for (uint32_t b0 = 0; b0 < cy; b0 += 64) {
+                const uint32_t cnt = min(64u, cy - b0);
+                const float v = (lane < cnt) ? row[ly[b0 + lane]] : 0.0f;
+                for (uint32_t t = 0; t < cnt; ++t)
+                    acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t));
+            }
         }
     }
     if (lane != 0) return;

@@ -65,6 +65,7 @@ struct CepsParams {
     const uint64_t *frame_off;    // [n_seq+1] first output frame of every recording
     uint32_t n_seq;
     uint64_t n_frames;
+    uint64_t first_frame;      // frames first_frame .. of this launch (launches stay below 2^31 work-items)
     uint32_t fft, step, L, fstep, K, log2n;
     const float *hamming;      // [fft]
     const float *triag;        // [L]
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void cepstrum_kernel(const CepsParams P)
     float *base = lds + (size_t)wave * (4 * N + half + 2 * P.K);
     float2 *bufa = reinterpret_cast<float2 *>(base), *bufb = bufa + N;
     float *mag = base + 4 * N, *conv = mag + half, *ceps = conv + P.K;
-    const uint64_t frame = (uint64_t)blockIdx.x * 4 + wave;
+    const uint64_t frame = P.first_frame + (uint64_t)blockIdx.x * 4 + wave;
     const bool live = frame < P.n_frames;
     uint32_t lo = 0, hi = P.n_seq;                                // recording holding this frame: largest s with frame_off[s] <= frame
     while (live && hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (P.frame_off[mid] <= frame) lo = mid; else hi = mid; }
@@ -312,8 +313,13 @@ static int cepstrum_impl(apd_context *ctx, const int16_t *samples, const uint64_
     if (rc == APD_OK && lds_bytes > 64 * 1024)
         guard(hipFuncSetAttribute(reinterpret_cast<const void *>(cepstrum_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     if (rc == APD_OK) {
-        hipLaunchKernelGGL(cepstrum_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), lds_bytes, ctx->stream, P);
-        guard(hipGetLastError());
+        constexpr uint64_t kFramesPerLaunch = 1ull << 24;                 // 2^22 workgroups of 256
+        for (uint64_t f0 = 0; f0 < T && rc == APD_OK; f0 += kFramesPerLaunch) {
+            P.first_frame = f0;
+            const uint64_t cnt = std::min(kFramesPerLaunch, T - f0);
+            hipLaunchKernelGGL(cepstrum_kernel, dim3((unsigned)((cnt + 3) / 4)), dim3(256), lds_bytes, ctx->stream, P);
+            guard(hipGetLastError());
+        }
     }
     if (!on_device && rc == APD_OK) guard(hipMemcpyAsync(out, pool + out_off, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     guard(hipStreamSynchronize(ctx->stream));

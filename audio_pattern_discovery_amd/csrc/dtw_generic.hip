@@ -243,7 +243,28 @@ int pick_full_key(uint32_t cols, uint32_t dim, int variant)
     return 0;
 }
 
+static hipError_t launch_align_chunk(const AlignLaunch &L, int geom_key, hipStream_t stream, std::string &err, int *status);
+
+// A launch may not exceed 2^32 work-items (beyond, the grid is silently cut short on this runtime): launches are cut
+// into runs of tiles that stay below 2^31.  Work-items per tile: 256 pairs x lanes per pair.
 hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, std::string &err, int *status)
+{
+    *status = APD_OK;
+    uint32_t lanes_per_pair = 64;                                         // generic kernel: one wavefront per pair
+    if (geom_key >= 10000) lanes_per_pair = 64u * (uint32_t)((geom_key % 10000) / 100);   // wide / full-matrix: NW waves per pair
+    else if (geom_key != 0) lanes_per_pair = (uint32_t)(geom_key / 100);                   // systolic: G lanes per pair
+    const uint32_t kTilesPerLaunch = (1u << 31) / (kSlotsPerTile * std::max(lanes_per_pair, 64u));
+    for (uint32_t first = 0; first < L.n_tiles; first += kTilesPerLaunch) {
+        AlignLaunch part = L;
+        part.d_tiles = L.d_tiles + first;
+        part.n_tiles = std::min(kTilesPerLaunch, L.n_tiles - first);
+        const hipError_t e = launch_align_chunk(part, geom_key, stream, err, status);
+        if (e != hipSuccess || *status != APD_OK) return e;
+    }
+    return hipSuccess;
+}
+
+static hipError_t launch_align_chunk(const AlignLaunch &L, int geom_key, hipStream_t stream, std::string &err, int *status)
 {
     *status = APD_OK;
     if (L.n_tiles == 0) return hipSuccess;

@@ -44,6 +44,9 @@ WORKLOADS["cfg5s"] = dict(n_seq=512, length=2048, dim=13, pct=0.0625,
 WORKLOADS["cfg5e"] = dict(n_seq=256, length=2048, dim=13, pct=0.0625, audio=True,
                           desc="cfg 5's end-to-end data path at 1/64 of its sequence count: 256 recordings x 262400 i16 samples -> on-device "
                                "cepstrum (spectrogram.rs:31-80, dft_win 256, step 128, ceps_filter 18 -> 13 bins) -> DTW band=128 (not a BASELINE config)")
+WORKLOADS["cfg5"] = dict(n_seq=16384, length=2048, dim=13, pct=0.0625, audio=True,
+                         desc="cfg5: 16384 recordings x 262400 i16 samples -> on-device cepstrum (13 bins) -> DTW band=128 "
+                              "(add --cluster for the UPGMA leg); ~1 min per step on one GPU")
 WORKLOADS["ship"] = dict(n_seq=512, length=525, jitter=375, dim=10, pct=1.0, encode_from=26,
                          desc="the reference's shipped Discovery.toml shape: 512 ragged VAT slices of 150..900 frames, 26-bin cepstra -> "
                               "10-dim autoencoder embeddings on-device -> full DTW (warping_band_percentage = 1.0); not a BASELINE config")
@@ -147,8 +150,8 @@ def main():
         rng_a = np.random.default_rng(0xA0D10)
         n_samp = 256 + 128 * wl["length"]
         base = [synth.make_audio(n_samp, seed=1000 + k) for k in range(16)]
-        audio = [np.clip(base[k % 16].astype(np.int32) + rng_a.integers(-200 * (k // 16), 200 * (k // 16) + 1, n_samp), -32768, 32767).astype(np.int16)
-                 for k in range(n)]
+        audio = [np.clip(base[k % 16].astype(np.int32) + rng_a.integers(-200 * min(k // 16, 40), 200 * min(k // 16, 40) + 1, n_samp, dtype=np.int16),
+                         -32768, 32767).astype(np.int16) for k in range(n)]
     frames, offsets = (None, None) if audio is not None else synth.make_sequences(n, wl["length"], src_dim, seed=0xA9D0 + sum(map(ord, args.workload)) % 97, jitter=wl.get("jitter"))
     if audio is not None:
         s_off = np.concatenate([[0], np.cumsum([len(a) for a in audio])]).astype(np.uint64)

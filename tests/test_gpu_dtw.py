@@ -350,3 +350,36 @@ def test_multi_wave_kernels_are_deterministic(ctx, oracle, dim, lo, hi, pct):
     for r in runs[1:]:
         assert np.array_equal(runs[0], r)
     assert_parity(runs[0], oracle.align_all(frames, offsets, pct, workers=16))
+
+
+def test_launches_are_cut_below_the_work_item_limit(ctx, oracle):
+    """11700 short sequences on a 64-lanes-per-pair kernel: 268 278 tiles x 16 384 work-items exceed 2^32, beyond which the
+    runtime cuts a grid short without an error; launch_align issues runs of tiles instead.  (cfg 5 -- 16384 recordings,
+    band 128 -- is the BASELINE configuration that crosses this limit.)"""
+    import torch
+    from audio_pattern_discovery_amd import _lib
+    n, dim = 11700, 13
+    rng = np.random.default_rng(3)
+    lens = rng.integers(50, 55, n)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    frames = rng.standard_normal((int(offsets[-1]), dim)).astype(np.float32)
+    L = _lib.lib()
+    d_frames = torch.from_numpy(frames).cuda()
+    batch = C.c_void_p()
+    _lib.check(L.apd_batch_create(ctx.handle, C.c_void_p(d_frames.data_ptr()), offsets.ctypes.data_as(C.POINTER(C.c_uint64)), n, dim, 1,
+                                  C.byref(batch)), ctx.handle)
+    cfg = _lib.AlignConfig(1.0, 1.0, 1.0, 1.0)
+    d_out = torch.empty(n * n, dtype=torch.float32, device="cuda")
+    _lib.check(L.apd_align_all_device_async(ctx.handle, batch, C.byref(cfg), C.c_void_p(d_out.data_ptr())), ctx.handle)
+    torch.cuda.synchronize()
+    order = np.argsort(-lens, kind="stable")                     # tiles follow the length order: sample its head, middle and tail
+    pos_i = np.concatenate([rng.integers(0, n, 200), [0, 1, n - 1, n - 2, n // 2]])
+    pos_j = np.concatenate([rng.integers(0, n, 200), [n - 1, n - 3, n - 5, 0, n - 1]])
+    keep = pos_i != pos_j
+    pi, pj = order[pos_i[keep]].astype(np.uint32), order[pos_j[keep]].astype(np.uint32)
+    want, _ = oracle.align_sample(frames, offsets, pi, pj, 1.0, workers=8)
+    got = d_out.view(n, n)[torch.from_numpy(pi.astype(np.int64)), torch.from_numpy(pj.astype(np.int64))].cpu().numpy()
+    L.apd_batch_destroy(batch)
+    assert_parity(got, want)
+    assert float(d_out.view(n, n).diagonal().abs().max()) == 0.0
+    assert int((d_out == 0).sum()) == n                          # nothing left unwritten: only the diagonal is zero

@@ -13,8 +13,13 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 perc = float(sys.argv[2]) if len(sys.argv) > 2 else 0.05
 torch.manual_seed(0)
 x = torch.randn(n, 8, device="cuda")
-centers = torch.randn(64, 8, device="cuda") * 4
-x = x * 0.5 + centers[torch.randint(0, 64, (n,), device="cuda")]
+n_centers = int(sys.argv[3]) if len(sys.argv) > 3 else 64          # 16: the family structure of bench.py's cfg 5 audio
+centers = torch.randn(n_centers, 8, device="cuda") * 4
+if len(sys.argv) > 4 and sys.argv[4] == "chain":                    # member k of a family sits at noise radius ~ k / 16: clusters grow one by one
+    k = torch.arange(n, device="cuda")
+    x = x * (0.02 + 2.0 * (k // n_centers).float()[:, None] / (n / n_centers)) + centers[k % n_centers]
+else:
+    x = x * 0.5 + centers[torch.randint(0, n_centers, (n,), device="cuda")]
 d = torch.cdist(x, x).contiguous()
 d.fill_diagonal_(0.0)
 ctx = _lib.Context(0)
