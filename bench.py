@@ -256,11 +256,12 @@ def main():
                 ref_frames = frames if enc_w is None else oracle.encode(frames, enc_w, enc_b)
                 want, _ = oracle.align_sample(ref_frames, offsets, pi, pj, wl["pct"], workers=host_threads())
             verify = float(np.max(np.abs(result[pi, pj] - want) / np.maximum(np.abs(want), 1e-30)))
-        traffic = None
+        traffic = valu_insts = None
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(args.workload)
             if rec and rec.get("n_gpus") == world:
                 traffic = rec["traffic_bytes"]        # measured by rocprofv3 PMC passes of this command (profiles/)
+                valu_insts = rec.get("sq_insts_valu")  # wavefront VALU instructions per launch (SQ_INSTS_VALU)
         except (OSError, ValueError):
             pass
         k_ms = float(np.mean(kernel_ms))
@@ -281,6 +282,14 @@ def main():
                          "kernel": "dtw_fused (rank 0 share: %d ordered pairs)" % pairs_r,
                          "kernel_ms": k_ms, "alg_bytes_per_launch": bytes_r,
                          "kernel_cells_per_s": cells_r / (k_ms * 1e-3)},
+            # the kernel is VALU-bound, so the HBM fraction above is reported next to the vector-issue figure:
+            # lane-instructions per cell from the SQ_INSTS_VALU counter of this workload, times the live cell rate, over the
+            # 3.9e13 lane-instr/s of 1024 SIMDs x 16 lanes x 2.4 GHz (MI355X issues simple f32 ops faster than that: > 1 is possible)
+            "valu": None if not valu_insts else {
+                "lane_instr_per_cell": valu_insts * 64.0 / cells_r,
+                "lane_instr_per_s": valu_insts * 64.0 / (k_ms * 1e-3),
+                "frac_of_16_lanes_per_simd_clk": valu_insts * 64.0 / (k_ms * 1e-3) / (1024 * 16 * 2.4e9),
+                "source": "profiles/hbm_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU)"},
             "max_rel_err_vs_oracle": verify, "parity_ok": (verify is None) or bool(verify <= (1e-3 if audio is not None else 1e-4)),
         }
         if args.cluster:
