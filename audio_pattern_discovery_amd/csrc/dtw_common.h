@@ -22,13 +22,24 @@ __device__ __forceinline__ float dpp_move(float v, float fill)
 __device__ __forceinline__ float from_lower_lane(float v, float fill) { return dpp_move<0x138>(v, fill); }
 __device__ __forceinline__ float from_upper_lane(float v, float fill) { return dpp_move<0x130>(v, fill); }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move_rows(float v, float keep)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xf, false));
+}
+
 // Shifts inside groups of G lanes: lane 0 of a group (no lower neighbour) / lane G-1 (no upper) gets `fill`.
-// G = 16 maps onto DPP rows; G = 64 onto the wave shifts; other sizes fix the group edges with a select.
+// G = 16 maps onto DPP rows and G = 64 onto the wave shifts (one instruction).  G = 32 takes two, each writing two of
+// the four 16-lane rows: the rows whose source crosses a row boundary inside a group use the wave shift, the rows
+// that end (begin) a group use the row shift, whose edge lane has no source and keeps `fill`.  Other sizes fix the
+// group edges with a select.
 template <int G>
 __device__ __forceinline__ float group_from_lower(float v, float fill, int gl)
 {
     if (G == 64) return dpp_move<0x138>(v, fill);
     if (G == 16) return dpp_move<0x111>(v, fill);
+    if (G == 32) return dpp_move_rows<0x111, 0x5>(v, dpp_move_rows<0x138, 0xA>(v, fill));   // rows 1,3 read across; rows 0,2 start a group
     const float t = dpp_move<0x138>(v, fill);
     return gl == 0 ? fill : t;
 }
@@ -37,6 +48,7 @@ __device__ __forceinline__ float group_from_upper(float v, float fill, int gl)
 {
     if (G == 64) return dpp_move<0x130>(v, fill);
     if (G == 16) return dpp_move<0x101>(v, fill);
+    if (G == 32) return dpp_move_rows<0x101, 0xA>(v, dpp_move_rows<0x130, 0x5>(v, fill));   // rows 0,2 read across; rows 1,3 end a group
     const float t = dpp_move<0x130>(v, fill);
     return gl == G - 1 ? fill : t;
 }

@@ -160,6 +160,8 @@ __global__ void selftest_kernel(int *result)
     ok &= group_from_lower<16>(v, -3.0f, lane % 16) == (lane % 16 == 0 ? -3.0f : (float)(lane - 1));
     ok &= group_from_upper<16>(v, -4.0f, lane % 16) == (lane % 16 == 15 ? -4.0f : (float)(lane + 1));
     ok &= group_from_lower<32>(v, -5.0f, lane % 32) == (lane % 32 == 0 ? -5.0f : (float)(lane - 1));
+    ok &= group_from_upper<32>(v, -7.0f, lane % 32) == (lane % 32 == 31 ? -7.0f : (float)(lane + 1));
+    ok &= group_from_upper<32>(v, (float)(100 + lane), lane % 32) == (lane % 32 == 31 ? (float)(100 + lane) : (float)(lane + 1));   // per-lane keep value
     ok &= group_from_upper<8>(v, -6.0f, lane % 8) == (lane % 8 == 7 ? -6.0f : (float)(lane + 1));
     const unsigned long long all = __ballot(ok);
     if (lane == 0) *result = (all == ~0ull) ? 1 : 0;
@@ -211,12 +213,13 @@ int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen
         const int g = variant / 100, c = variant % 100;
         return ((uint32_t)(g * c) >= need) ? variant : 0;
     }
-    static const Geometry all[] = {{16, 2}, {16, 3}, {16, 5}, {16, 9}, {64, 3}, {64, 5}, {64, 9}};   // (8, 9) only on request
+    static const Geometry all[] = {{16, 2}, {16, 3}, {16, 5}, {16, 9}, {32, 5}, {32, 9}, {64, 3}, {64, 5}, {64, 9}};   // (8, 9) only on request
     Geometry best{0, 0};
     double best_util = 0.0;
     for (const Geometry &q : all) {
         if ((uint32_t)(q.g * q.c) < need || q.c > max_cells_per_lane(dim)) continue;
-        const double util = (double)need / (double)(q.g * q.c) - 0.004 * (9 - q.c);   // larger C: fewer exchanges per cell
+        const double util = (double)need / (double)(q.g * q.c) - 0.004 * (9 - q.c)   // larger C: fewer exchanges per cell
+                            - (q.g == 32 ? 0.04 : 0.0);                                // G = 32: two DPP per cross-lane move
         if (util > best_util) { best_util = util; best = q; }
     }
     if (best.g != 0) return best.g * 100 + best.c;

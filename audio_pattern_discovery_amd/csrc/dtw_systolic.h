@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     asm volatile("" : "+v"(ins), "+v"(del), "+v"(mat), "+v"(tau_thr));   // keep them in VGPRs: an SGPR operand doubles a VOP2's issue cost
     // row-frame ring of this wave: slot = row & (R - 1); rows <= 0 hold -INF.  R > 2U + G - 2 keeps a refill from
     // overwriting a row some lane still needs.
-    constexpr int R = (G == 64) ? 128 : 64;
+    constexpr int R = (G == 64) ? 128 : 64;                      // G = 32, U <= 10: 2U + G - 2 = 50 < 64
     constexpr int LPF = DP / 4;                                  // lanes (16-byte pieces) per frame
     constexpr int FPF = 64 / LPF;                                // frames per wave-wide fill
     __shared__ float xring_all[4][R * DP];
@@ -377,6 +377,7 @@ bool launch_systolic(const AlignLaunch &L, int g, int c, bool unit, hipStream_t 
 #define APD_CASE(GG, CC) if constexpr (CC <= max_cells_per_lane(D)) { if (g == GG && c == CC) { launch_systolic_cg<D, CC, GG>(L, unit, stream); return true; } }
     APD_CASE(8, 9)
     APD_CASE(16, 2) APD_CASE(16, 3) APD_CASE(16, 5) APD_CASE(16, 9)
+    APD_CASE(32, 5) APD_CASE(32, 9)
     APD_CASE(64, 3) APD_CASE(64, 5) APD_CASE(64, 9)
 #undef APD_CASE
     return false;

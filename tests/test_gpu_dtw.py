@@ -383,3 +383,33 @@ def test_launches_are_cut_below_the_work_item_limit(ctx, oracle):
     assert_parity(got, want)
     assert float(d_out.view(n, n).diagonal().abs().max()) == 0.0
     assert int((d_out == 0).sum()) == n                          # nothing left unwritten: only the diagonal is zero
+
+
+@pytest.mark.parametrize("dim", [13, 26])
+@pytest.mark.parametrize("key", [809, 1602, 1603, 1605, 1609, 3205, 3209, 6403, 6405, 6409])
+def test_every_systolic_geometry(ctx, oracle, key, dim):
+    """Each (lanes per pair G, offsets per lane C) of dtw_fused_systolic, forced through the tuning variant, on a band that
+    fills its lanes (2w+1 just below G*C) and on a narrow one (idle upper lanes); unit penalties in both distance forms,
+    and unequal penalties (bit-identical to the oracle).  G = 32 moves data across lanes with two DPP writes per move."""
+    g, c = key // 100, key % 100
+    if c == 9 and dim > 13:
+        pytest.skip("C = 9 is instantiated for D <= 13")
+    from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
+    from audio_pattern_discovery_amd.discovery import Discovery
+    length = 300
+    for band in ((g * c - 1) // 2 - 2, 3):
+        pct = (band + 0.5) / length
+        frames, offsets = synth.make_sequences(20, length, dim, seed=key + dim + band, jitter=0)
+        seqs = [NDSequence(s) for s in synth.split(frames, offsets)]
+        for pens, mode in (((1.0, 1.0, 1.0), "hybrid"), ((1.0, 1.0, 1.0), "exact"), ((0.6, 1.3, 1.0), "hybrid")):
+            want = oracle.align_all(frames, offsets, pct, *pens, workers=8)
+            ctx.set_distance_mode(mode)
+            ctx.set_variant(key)
+            got = AlignmentWorkers.new(seqs, ctx).align_all(Discovery(warping_band_percentage=pct, insertion_penalty=pens[0],
+                                                                      deletion_penalty=pens[1], match_penalty=pens[2])).reshape(20, 20)
+            ctx.set_variant(0)
+            ctx.set_distance_mode("hybrid")
+            if pens == (1.0, 1.0, 1.0):
+                assert_parity(got, want)
+            else:
+                assert np.array_equal(got, want)
