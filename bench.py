@@ -50,6 +50,8 @@ WORKLOADS["cfg5"] = dict(n_seq=16384, length=2048, dim=13, pct=0.0625, audio=Tru
 WORKLOADS["ship"] = dict(n_seq=512, length=525, jitter=375, dim=10, pct=1.0, encode_from=26,
                          desc="the reference's shipped Discovery.toml shape: 512 ragged VAT slices of 150..900 frames, 26-bin cepstra -> "
                               "10-dim autoencoder embeddings on-device -> full DTW (warping_band_percentage = 1.0); not a BASELINE config")
+WORKLOADS["wide7"] = dict(n_seq=128, length=4000, dim=13, pct=0.1,
+                          desc="128 seq len~4000 D=13, band=400: a binding band wider than one wavefront (dtw_fused_wide; not a BASELINE config)")
 WORKLOADS["full6"] = dict(n_seq=256, length=600, dim=13, pct=1.0,
                           desc="256 seq len~600 D=13, full DTW (the reference's shipped warping_band_percentage = 1.0 on long slices; not a BASELINE config)")
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec

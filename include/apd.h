@@ -81,10 +81,14 @@ int apd_set_timing(apd_context *ctx, int enabled);
 float apd_last_kernel_ms(apd_context *ctx);
 /* Tuning knob for experiments: 0 = pick automatically.  See DESIGN.md "Kernel variants". */
 int apd_set_variant(apd_context *ctx, int variant);
-/* Local-distance form of the fast kernel.  mode 0: sqrt(sum (x_k-y_k)^2) as the reference computes it (fma chain).
- * mode 1 (default): |x|^2 + |y|^2 - 2 x.y from precomputed frame norms, recomputed in the difference form wherever
- * the result is below tau * (|x|^2 + |y|^2) (cancellation region; tau <= 0 keeps the current value, default 1/64):
- * 9 fewer vector ops per cell, distances within ~1e-5 relative instead of ~2e-7 (tolerance asked: 1e-4). */
+/* Local-distance form of the fast kernels with UNIT penalties (1.0, 1.0, 1.0 -- the shipped Discovery.toml).
+ * mode 0: sqrt(sum (x_k-y_k)^2) as an fma chain, ~2e-7 relative of the reference.  mode 1 (default, D >= 10):
+ * |x|^2 + |y|^2 - 2 x.y from precomputed frame norms, recomputed in the difference form wherever the result is below
+ * tau * (|x|^2 + |y|^2) (cancellation region; tau <= 0 keeps the current value, default 1/64): 9 fewer vector ops
+ * per cell, ~3e-7 relative measured (tolerance asked: 1e-4); exact copies score exactly 0 in both.
+ * With any other penalties the recurrence is discontinuous in its inputs (the penalty added depends on which
+ * predecessor wins a strict comparison), so the library ignores the mode and computes operation for operation as
+ * numerics.rs:114-120 / alignments.rs:129-160 do: results are then bit-identical to the CPU arithmetic. */
 int apd_set_distance_mode(apd_context *ctx, int mode, float tau);
 /* Device self-test of the cross-lane primitives the kernels rely on (DPP wave shifts). */
 int apd_selftest(apd_context *ctx);
@@ -172,19 +176,20 @@ int apd_cepstrum(apd_context *ctx, const int16_t *samples, uint64_t n_samples, u
                  uint32_t fft_step, uint32_t filter_size, int on_device, float *out, uint64_t *n_frames,
                  uint32_t *n_bins);
 
-/* NDSequence::interesting_ranges (src/spectrogram.rs:174-216), the "VAT" pre-segmentation that precedes the path:
- * per-frame std, mean of the `moving_average` previous values, percentile threshold, runs longer than min_len.
- * frames: [t][n_bins] (device if on_device).  ranges: (start, stop) frame pairs, host; *n_ranges may exceed capacity. */
-int apd_interesting_ranges(apd_context *ctx, const float *frames, uint64_t t, uint32_t n_bins, uint32_t moving_average,
-                           float perc, uint64_t min_len, int on_device, uint64_t *ranges, uint64_t capacity,
-                           uint64_t *n_ranges);
-/* The same for n_seq recordings stored back to back (sample_offsets: n_seq+1): one launch for the whole corpus.
+/* apd_cepstrum for n_seq recordings stored back to back (sample_offsets: n_seq+1): one launch for the whole corpus.
  * frame_offsets (n_seq+1, host, always written) and out ([frame_offsets[n_seq]][*n_bins], packed) are exactly the
  * `offsets` / `frames` arguments of apd_batch_create, so with on_device != 0 features go from audio to the
  * alignment without leaving HBM.  out may be NULL to query sizes. */
 int apd_cepstrum_batch(apd_context *ctx, const int16_t *samples, const uint64_t *sample_offsets, uint32_t n_seq,
                        uint32_t fft_size, uint32_t fft_step, uint32_t filter_size, int on_device, float *out,
                        uint64_t *frame_offsets, uint32_t *n_bins);
+
+/* NDSequence::interesting_ranges (src/spectrogram.rs:174-216), the "VAT" pre-segmentation that precedes the path:
+ * per-frame std, mean of the `moving_average` previous values, percentile threshold, runs longer than min_len.
+ * frames: [t][n_bins] (device if on_device).  ranges: (start, stop) frame pairs, host; *n_ranges may exceed capacity. */
+int apd_interesting_ranges(apd_context *ctx, const float *frames, uint64_t t, uint32_t n_bins, uint32_t moving_average,
+                           float perc, uint64_t min_len, int on_device, uint64_t *ranges, uint64_t capacity,
+                           uint64_t *n_ranges);
 
 #ifdef __cplusplus
 }
