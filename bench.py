@@ -294,6 +294,21 @@ def main():
                 "source": "profiles/hbm_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU)"},
             "max_rel_err_vs_oracle": verify, "parity_ok": (verify is None) or bool(verify <= (1e-3 if audio is not None else 1e-4)),
         }
+        if frames is not None and enc_w is None and world == 1:
+            # the host-buffer entry of the boundary (AlignmentWorkers::new + align_all on host Vec<f32>s): H2D of the frames,
+            # repack, kernel, unpack, D2H of the matrix -- reported beside `value`, never as it
+            host_out = np.empty(n * n, dtype=np.float32)
+            hb = C.c_void_p()
+            t0 = time.perf_counter()
+            _lib.check(L.apd_batch_create(ctx.handle, frames.ctypes.data_as(f32p), off_c.ctypes.data_as(C.POINTER(C.c_uint64)), n, dim, 0,
+                                          C.byref(hb)), ctx.handle)
+            _lib.check(L.apd_align_all(ctx.handle, hb, C.byref(cfg), host_out.ctypes.data_as(f32p)), ctx.handle)
+            dt = time.perf_counter() - t0
+            L.apd_batch_destroy(hb)
+            line["pcie_inclusive"] = {"seconds": dt, "value": cells_all / dt, "unit": "cell-updates/s",
+                                      "h2d_bytes": int(frames.nbytes), "d2h_bytes": int(host_out.nbytes),
+                                      "bitwise_equal_to_resident_path": bool(np.array_equal(host_out.reshape(n, n), result)),
+                                      "note": "apd_batch_create(host frames) + apd_align_all(host out), pageable host memory, one call"}
         if args.cluster:
             ops = (_lib.ClusterOp * n)()
             roots = np.zeros(n, dtype=np.uint32)
