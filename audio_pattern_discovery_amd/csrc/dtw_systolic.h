@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
         fill_load(1, regs);
         fill_store(1, regs);
     }
+    asm volatile("" ::: "memory");
     auto read_row = [&](float (&dst)[DN], int row) __attribute__((always_inline)) {
         const float *p = &xring[(row & (R - 1)) * DP];
 #pragma unroll
@@ -340,6 +341,9 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                 }
             }
             fill_store(tau0 + U + 1, fill_regs);
+            asm volatile("" ::: "memory");                       // rows written by other lanes are read in the next block: no
+                                                                 // barrier needed inside one wave (LDS runs in order), but the
+                                                                 // compiler must not move the reads up
         }
     };
     macro_steps(0, a_end, std::true_type{});
