@@ -48,7 +48,7 @@ constexpr int kKernelDims[] = {8, 10, 13, 16, 20, 26};
 constexpr bool is_kernel_dim(uint32_t d) { for (int k : kKernelDims) if ((uint32_t)k == d) return true; return false; }
 constexpr uint32_t kernel_dim(uint32_t d) { for (int k : kKernelDims) if ((uint32_t)k >= d) return (uint32_t)k; return d; }
 // Cells per lane the register file holds: (C + 2) frames of ceil4(D + 1) floats plus ~50 registers of state.
-constexpr int max_cells_per_lane(uint32_t d) { return d <= 13 ? 9 : 5; }
+constexpr int max_cells_per_lane(uint32_t d) { return d <= 13 ? 9 : (d <= 16 ? 7 : 5); }
 
 // geom_key = G * 100 + C of the systolic kernel, or 0 for the generic kernel (see pick_geometry_key)
 hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, std::string &err, int *status);

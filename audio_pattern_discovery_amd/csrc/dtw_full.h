@@ -190,7 +190,8 @@ template <int D>
 bool launch_full(const AlignLaunch &L, int nw, int cw, hipStream_t stream, hipError_t *err)
 {
 #define APD_FCASE(NN, CC) if constexpr (CC <= max_cells_per_lane(D)) { if (nw == NN && cw == CC) { *err = launch_full_cn<D, CC, NN>(L, stream); return true; } }
-    APD_FCASE(1, 3) APD_FCASE(1, 5) APD_FCASE(1, 9) APD_FCASE(2, 9) APD_FCASE(4, 5) APD_FCASE(4, 9) APD_FCASE(8, 5) APD_FCASE(8, 9)
+    APD_FCASE(1, 3) APD_FCASE(1, 5) APD_FCASE(1, 7) APD_FCASE(1, 9) APD_FCASE(2, 5) APD_FCASE(2, 7) APD_FCASE(2, 9)
+    APD_FCASE(4, 5) APD_FCASE(4, 7) APD_FCASE(4, 9) APD_FCASE(8, 5) APD_FCASE(8, 7) APD_FCASE(8, 9)
 #undef APD_FCASE
     return false;
 }

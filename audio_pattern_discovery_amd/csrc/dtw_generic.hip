@@ -204,6 +204,7 @@ struct Geometry { int g, c; };
 int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen)
 {
     if (variant == 1) return 0;                                        // forced generic kernel
+    if (variant >= 20000) variant = 0;                                 // a forced full-matrix geometry (pick_full_key) says nothing about band-form tiles
     if (!is_kernel_dim(dim)) return 0;                                 // instantiated frame dimensions
     if (variant >= 10000) {                                            // forced wide geometry (tuning)
         const int nw = (variant - 10000) / 100, c = variant % 100;
@@ -213,7 +214,7 @@ int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen
         const int g = variant / 100, c = variant % 100;
         return ((uint32_t)(g * c) >= need) ? variant : 0;
     }
-    static const Geometry all[] = {{16, 2}, {16, 3}, {16, 5}, {16, 9}, {32, 5}, {32, 9}, {64, 3}, {64, 5}, {64, 9}};   // (8, 9) only on request
+    static const Geometry all[] = {{16, 2}, {16, 3}, {16, 5}, {16, 7}, {16, 9}, {32, 5}, {32, 7}, {32, 9}, {64, 3}, {64, 5}, {64, 7}, {64, 9}};   // (8, 9) only on request
     Geometry best{0, 0};
     double best_util = 0.0;
     for (const Geometry &q : all) {
@@ -225,7 +226,7 @@ int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen
     if (best.g != 0) return best.g * 100 + best.c;
     // beyond one wavefront: NW waves per pair (dtw_wide.h), uniform penalties only
     if (uniform_pen) {
-        static const Geometry wide[] = {{2, 5}, {2, 9}, {4, 5}, {4, 9}, {8, 5}, {8, 9}};   // (NW, C), ascending capacity
+        static const Geometry wide[] = {{2, 5}, {2, 7}, {2, 9}, {4, 5}, {4, 7}, {4, 9}, {8, 5}, {8, 7}, {8, 9}};   // (NW, C), ascending capacity
         for (const Geometry &q : wide)
             if ((uint32_t)(64 * q.g * q.c) >= need && q.c <= max_cells_per_lane(dim)) return 10000 + q.g * 100 + q.c;
     }
@@ -240,7 +241,7 @@ int pick_full_key(uint32_t cols, uint32_t dim, int variant)
         const int nw = (variant - 20000) / 100, cw = variant % 100;
         return ((uint32_t)(64 * nw * cw) >= cols) ? variant : 0;
     }
-    static const Geometry full[] = {{1, 3}, {1, 5}, {1, 9}, {2, 9}, {4, 5}, {4, 9}, {8, 5}, {8, 9}};   // (NW, CW), ascending capacity
+    static const Geometry full[] = {{1, 3}, {1, 5}, {1, 7}, {1, 9}, {2, 5}, {2, 7}, {2, 9}, {4, 5}, {4, 7}, {4, 9}, {8, 5}, {8, 7}, {8, 9}};   // (NW, CW), ascending capacity
     for (const Geometry &q : full)
         if ((uint32_t)(64 * q.g * q.c) >= cols && q.c <= max_cells_per_lane(dim)) return 20000 + q.g * 100 + q.c;
     return 0;

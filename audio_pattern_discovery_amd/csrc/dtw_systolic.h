@@ -380,9 +380,9 @@ bool launch_systolic(const AlignLaunch &L, int g, int c, bool unit, hipStream_t 
     // C = 9 keeps 10 column frames per lane in registers: only for D <= 13 (max_cells_per_lane)
 #define APD_CASE(GG, CC) if constexpr (CC <= max_cells_per_lane(D)) { if (g == GG && c == CC) { launch_systolic_cg<D, CC, GG>(L, unit, stream); return true; } }
     APD_CASE(8, 9)
-    APD_CASE(16, 2) APD_CASE(16, 3) APD_CASE(16, 5) APD_CASE(16, 9)
-    APD_CASE(32, 5) APD_CASE(32, 9)
-    APD_CASE(64, 3) APD_CASE(64, 5) APD_CASE(64, 9)
+    APD_CASE(16, 2) APD_CASE(16, 3) APD_CASE(16, 5) APD_CASE(16, 7) APD_CASE(16, 9)
+    APD_CASE(32, 5) APD_CASE(32, 7) APD_CASE(32, 9)
+    APD_CASE(64, 3) APD_CASE(64, 5) APD_CASE(64, 7) APD_CASE(64, 9)
 #undef APD_CASE
     return false;
 }

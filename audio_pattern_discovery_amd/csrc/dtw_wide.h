@@ -243,7 +243,7 @@ template <int D>
 bool launch_wide(const AlignLaunch &L, int nw, int c, hipStream_t stream, hipError_t *err)
 {
 #define APD_WCASE(NN, CC) if constexpr (CC <= max_cells_per_lane(D)) { if (nw == NN && c == CC) { *err = launch_wide_cn<D, CC, NN>(L, stream); return true; } }
-    APD_WCASE(2, 5) APD_WCASE(2, 9) APD_WCASE(4, 5) APD_WCASE(4, 9) APD_WCASE(8, 5) APD_WCASE(8, 9)
+    APD_WCASE(2, 5) APD_WCASE(2, 7) APD_WCASE(2, 9) APD_WCASE(4, 5) APD_WCASE(4, 7) APD_WCASE(4, 9) APD_WCASE(8, 5) APD_WCASE(8, 7) APD_WCASE(8, 9)
 #undef APD_WCASE
     return false;
 }
