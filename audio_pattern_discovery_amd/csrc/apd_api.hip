@@ -410,7 +410,7 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
             // where four pairs per wavefront in band form keep more lanes busy.
             const uint32_t cols = std::min(hi[tiles[t].x], hi[tiles[t].y]);
             if (fast_ok && uniform_pen && mx >= 3 && std::min(band_ub, mx) >= mx - 3 && (cols >= 49 || ctx->variant >= 20000)) {
-                const int fk = pick_full_key(cols > 0 ? cols - 1 : 0, batch->dim, ctx->variant);
+                const int fk = pick_full_key(cols > 0 ? cols - 1 : 0, mx, batch->dim, ctx->variant);
                 if (fk != 0) key = fk;
             }
             groups[key].push_back(make_uint4(tiles[t].x, tiles[t].y, t, 0));

@@ -233,18 +233,21 @@ int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen
     return 0;
 }
 
-int pick_full_key(uint32_t cols, uint32_t dim, int variant)
+// Full-matrix kernel: 20100 + CW.  A pair of `rows` x `cols` takes ceil(cols / (64 CW)) passes of rows + 64 macro-steps, a
+// macro-step costs about CW + 2 cell times: the strip width with the smallest product wins.
+int pick_full_key(uint32_t cols, uint32_t rows, uint32_t dim, int variant)
 {
     if (variant != 0 && variant < 20000) return 0;                     // another kernel was requested
-    if (!is_kernel_dim(dim)) return 0;
-    if (variant >= 20000) {
-        const int nw = (variant - 20000) / 100, cw = variant % 100;
-        return ((uint32_t)(64 * nw * cw) >= cols) ? variant : 0;
+    if (!is_kernel_dim(dim) || rows > 32768) return 0;                 // the boundary column of a pass is rows floats of LDS
+    if (variant >= 20000) return ((variant - 20000) / 100 == 1) ? variant : 0;
+    int best = 0;
+    double best_cost = 0.0;
+    for (int cw = 3; cw <= max_strip_columns(dim); cw += 2) {
+        const double passes = (double)((cols + 64u * cw - 1) / (64u * cw));
+        const double cost = passes * ((double)rows + 64.0) * (cw + 2.0);
+        if (best == 0 || cost < best_cost) { best = cw; best_cost = cost; }
     }
-    static const Geometry full[] = {{1, 3}, {1, 5}, {1, 7}, {1, 9}, {2, 5}, {2, 7}, {2, 9}, {4, 5}, {4, 7}, {4, 9}, {8, 5}, {8, 7}, {8, 9}};   // (NW, CW), ascending capacity
-    for (const Geometry &q : full)
-        if ((uint32_t)(64 * q.g * q.c) >= cols && q.c <= max_cells_per_lane(dim)) return 20000 + q.g * 100 + q.c;
-    return 0;
+    return 20100 + best;
 }
 
 static hipError_t launch_align_chunk(const AlignLaunch &L, int geom_key, hipStream_t stream, std::string &err, int *status);
