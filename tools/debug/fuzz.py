@@ -17,7 +17,7 @@ t0 = time.time()
 for case in range(n_cases):
     dim = int(rng.choice([1, 2, 3, 5, 8, 9, 10, 12, 13, 15, 16, 19, 20, 23, 26, 27, 33]))
     n_seq = int(rng.integers(2, 50))
-    length = int(rng.choice([3, 8, 20, 60, 150, 400, 900]))
+    length = int(rng.choice([3, 8, 20, 60, 150, 400, 900, 1700, 2600]))
     jitter = int(rng.integers(0, max(length - 1, 1)))
     pct = float(rng.choice([0.0, 0.01, 0.0625, 0.1, 0.25, 0.5, 0.9, 1.0, 1.5]))
     integer = bool(rng.random() < 0.4)
@@ -25,7 +25,7 @@ for case in range(n_cases):
     pens = (1.0, 1.0, 1.0) if pk < 0.5 else ((0.7, 0.7, 0.7) if pk < 0.65 else tuple(float(v) for v in rng.choice([0.25, 0.5, 0.8, 1.0, 1.2, 2.0], 3)))
     mode = "hybrid" if rng.random() < 0.6 else "exact"
     if length >= 400:
-        n_seq = min(n_seq, 14)
+        n_seq = min(n_seq, 14 if length < 1700 else 7)
     frames, offsets = synth.make_sequences(n_seq, length, dim, seed=int(rng.integers(1 << 30)), integer=integer, jitter=jitter,
                                            copies=float(rng.choice([0.0, 0.25, 0.6])))
     want = oracle.align_all(frames, offsets, pct, *pens, workers=16)
