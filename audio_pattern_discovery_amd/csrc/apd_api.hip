@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -416,11 +417,51 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
             groups[key].push_back(make_uint4(tiles[t].x, tiles[t].y, t, 0));
             wmax[key] = std::max(wmax[key], w);
         }
+        // Every class is a launch of its own, and launches of one stream do not overlap: a full-matrix class of a few dozen
+        // tiles would run at a fraction of the machine.  Small classes (all of them, in a small batch) move to the geometry
+        // that is best for the full-matrix tiles as a whole.
+        if (ctx->variant == 0) {
+            auto dims_of = [&](const uint4 &t, uint32_t *cols, uint32_t *rows) {
+                *rows = std::max(hi[t.x], hi[t.y]);
+                const uint32_t c = std::min(hi[t.x], hi[t.y]);
+                *cols = c > 0 ? c - 1 : 0;
+            };
+            size_t n_full = 0;
+            for (auto &g : groups) if (g.first >= 20000) n_full += g.second.size();
+            int global_key = 0;
+            double global_cost = INFINITY;
+            for (int ppw = 1; ppw <= 4 && n_full > 0; ppw *= 2)
+                for (int cw = 5; cw <= max_strip_columns(batch->dim); cw += 2) {
+                    const int k = 20000 + ppw * 100 + cw;
+                    double total = 0.0;
+                    for (auto &g : groups) {
+                        if (g.first < 20000) continue;
+                        for (const uint4 &t : g.second) { uint32_t c, r; dims_of(t, &c, &r); total += full_key_cost(c, r, batch->dim, k); }
+                    }
+                    if (total < global_cost) { global_cost = total; global_key = k; }
+                }
+            const size_t min_class = n_full < 2048 ? n_full + 1 : 256;
+            if (global_key != 0) {
+                std::vector<int> small;
+                for (auto &g : groups) if (g.first >= 20000 && g.first != global_key && g.second.size() < min_class) small.push_back(g.first);
+                for (int k : small) {
+                    std::vector<uint4> &from = groups[k], &to = groups[global_key];
+                    to.insert(to.end(), from.begin(), from.end());
+                    wmax[global_key] = std::max(wmax[global_key], wmax[k]);
+                    groups.erase(k);
+                    wmax.erase(k);
+                }
+                std::sort(groups[global_key].begin(), groups[global_key].end(), [](const uint4 &a, const uint4 &b) { return a.z < b.z; });
+            }
+        }
         std::vector<uint4> flat;
         for (auto &g : groups) {
             plan.classes.push_back(apd_batch::TileClass{g.first, (uint32_t)flat.size(), (uint32_t)g.second.size(), wmax[g.first]});
             flat.insert(flat.end(), g.second.begin(), g.second.end());
         }
+        if (std::getenv("APD_DEBUG_PLAN"))                                  // tuning aid: which kernel geometry got how many tiles
+            for (const apd_batch::TileClass &tc : plan.classes)
+                std::fprintf(stderr, "[apd] rank %u/%u: geometry %d: %u tiles, w_max %u\n", rank, world, tc.geom_key, tc.count, tc.w_max);
         HIP_TRY(ctx, hipMalloc((void **)&plan.d_tiles, std::max<size_t>(flat.size(), 1) * sizeof(uint4)));
         if (!flat.empty()) {
             HIP_TRY(ctx, hipMemcpyAsync(plan.d_tiles, flat.data(), flat.size() * sizeof(uint4), hipMemcpyHostToDevice, ctx->stream));

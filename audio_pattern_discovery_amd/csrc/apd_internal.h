@@ -50,13 +50,14 @@ constexpr uint32_t kernel_dim(uint32_t d) { for (int k : kKernelDims) if ((uint3
 // Cells per lane the register file holds: (C + 2) frames of ceil4(D + 1) floats plus ~50 registers of state.
 constexpr int max_cells_per_lane(uint32_t d) { return d <= 13 ? 9 : (d <= 16 ? 7 : 5); }
 // Column strips of the full-matrix kernel hold CW frames per lane and one DP row: wider strips fit.
-constexpr int max_strip_columns(uint32_t d) { return d <= 13 ? 13 : max_cells_per_lane(d); }
+constexpr int max_strip_columns(uint32_t d) { return d <= 10 ? 13 : (d <= 13 ? 11 : max_cells_per_lane(d)); }   // 13 x 14 floats do not fit at D = 13
 
 // geom_key = G * 100 + C of the systolic kernel, or 0 for the generic kernel (see pick_geometry_key)
 hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, std::string &err, int *status);
 int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen);
-// >= 20000: full-matrix kernel, 20100 + CW, for pairs of at most `rows` x `cols` frames (0 if it does not apply)
+// >= 20000: full-matrix kernel, 20000 + (pairs per wavefront) * 100 + CW, for pairs of at most `rows` x `cols` frames (0 if it does not apply)
 int pick_full_key(uint32_t cols, uint32_t rows, uint32_t dim, int variant);   // (>= 10000: wide kernel, 10000 + NW * 100 + C)
+double full_key_cost(uint32_t cols, uint32_t rows, uint32_t dim, int key);    // modelled cost of one pair on that geometry (+inf: does not apply)
 hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_off, const uint32_t *d_src_off, uint32_t n_seq,
                       uint64_t n_frames_padded, uint32_t src_dim, uint32_t dim, uint32_t dpad, hipStream_t stream);
 hipError_t launch_unpack(const float *d_gathered, float *d_out, const uint32_t *d_order, uint32_t n_seq, uint32_t world,

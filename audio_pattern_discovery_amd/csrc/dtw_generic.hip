@@ -24,6 +24,7 @@
 // The kernel in this file is the slow, fully general one: any frame dimension, any band up to what 160 KB of LDS
 // holds (C chosen at run time, per-lane DP rows in LDS, every boundary tested per cell, any penalty values).
 // dtw_systolic.h holds the production kernel.
+#include <cmath>
 #include "dtw_common.h"
 
 namespace apd {
@@ -233,21 +234,40 @@ int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen
     return 0;
 }
 
-// Full-matrix kernel: 20100 + CW.  A pair of `rows` x `cols` takes ceil(cols / (64 CW)) passes of rows + 64 macro-steps, a
-// macro-step costs about CW + 2 cell times: the strip width with the smallest product wins.
+// Full-matrix kernel: 20000 + (pairs per wavefront) * 100 + CW.  With G = 64 / ppw lanes per pair, a pair of `rows` x `cols`
+// takes ceil(cols / (G CW)) passes of rows + G macro-steps, each serving ppw pairs.  The cost of a macro-step was fitted on
+// MI355X (tools/debug/strip_grid.sh: every forced geometry on bench.py's short9 / full6 / ship / full8): proportional to
+// CW (+0.5 / +1.5 for the two-DPP moves and per-lane bookkeeping of 32- / 16-lane groups), 8 % more once CW frames of D + 1
+// floats push the kernel to two waves per SIMD, and inversely to the wavefronts per CU that the LDS boundary columns
+// (ppw * rows floats per wavefront) leave room for.  Returns +inf for a geometry that is not instantiated or does not fit.
+double full_key_cost(uint32_t cols, uint32_t rows, uint32_t dim, int key)
+{
+    const int ppw = (key - 20000) / 100, cw = key % 100;
+    if (key < 20000 || !(ppw == 1 || ppw == 2 || ppw == 4) || cw < 3 || cw > max_strip_columns(dim) || cw % 2 == 0) return INFINITY;
+    const uint32_t g = 64u / ppw;
+    const double lds_bytes = 4.0 * ((g == 64 ? 128.0 : 64.0) * ((dim + 4) & ~3u) + (double)ppw * (rows + 4) + 16);
+    if (lds_bytes > 160.0 * 1024) return INFINITY;
+    const double waves_per_cu = std::floor(160.0 * 1024 / lds_bytes);
+    const double lds_factor = waves_per_cu >= 8.0 ? 1.0 : 8.0 / waves_per_cu;
+    const double group_steps = ppw == 1 ? 0.0 : (ppw == 2 ? 0.5 : 1.5);
+    const double occupancy_factor = (uint32_t)cw * (dim + 3) > 150 ? 1.08 : 1.0;
+    const double passes = (double)((cols + g * cw - 1) / (g * cw));
+    return passes * ((double)rows + g) * (cw + group_steps) * occupancy_factor * lds_factor / ppw;
+}
+
 int pick_full_key(uint32_t cols, uint32_t rows, uint32_t dim, int variant)
 {
     if (variant != 0 && variant < 20000) return 0;                     // another kernel was requested
-    if (!is_kernel_dim(dim) || rows > 32768) return 0;                 // the boundary column of a pass is rows floats of LDS
-    if (variant >= 20000) return ((variant - 20000) / 100 == 1) ? variant : 0;
+    if (!is_kernel_dim(dim)) return 0;
+    if (variant >= 20000) return std::isfinite(full_key_cost(cols, rows, dim, variant)) ? variant : 0;
     int best = 0;
-    double best_cost = 0.0;
-    for (int cw = 3; cw <= max_strip_columns(dim); cw += 2) {
-        const double passes = (double)((cols + 64u * cw - 1) / (64u * cw));
-        const double cost = passes * ((double)rows + 64.0) * (cw + 2.0);
-        if (best == 0 || cost < best_cost) { best = cw; best_cost = cost; }
-    }
-    return 20100 + best;
+    double best_cost = INFINITY;
+    for (int ppw = 1; ppw <= 4; ppw *= 2)
+        for (int cw = 5; cw <= max_strip_columns(dim); cw += 2) {          // 3-column strips only on request: measured slower than the model says
+            const double cost = full_key_cost(cols, rows, dim, 20000 + ppw * 100 + cw);
+            if (cost < best_cost) { best = 20000 + ppw * 100 + cw; best_cost = cost; }
+        }
+    return best;
 }
 
 static hipError_t launch_align_chunk(const AlignLaunch &L, int geom_key, hipStream_t stream, std::string &err, int *status);
@@ -258,7 +278,8 @@ hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, 
 {
     *status = APD_OK;
     uint32_t lanes_per_pair = 64;                                         // generic kernel: one wavefront per pair
-    if (geom_key >= 10000) lanes_per_pair = 64u * (uint32_t)((geom_key % 10000) / 100);   // wide / full-matrix: NW waves per pair
+    if (geom_key >= 20000) lanes_per_pair = 64;                                           // full-matrix: at most one wavefront per pair
+    else if (geom_key >= 10000) lanes_per_pair = 64u * (uint32_t)((geom_key % 10000) / 100);   // wide: NW waves per pair
     else if (geom_key != 0) lanes_per_pair = (uint32_t)(geom_key / 100);                   // systolic: G lanes per pair
     const uint32_t kTilesPerLaunch = (1u << 31) / (kSlotsPerTile * std::max(lanes_per_pair, 64u));
     for (uint32_t first = 0; first < L.n_tiles; first += kTilesPerLaunch) {

@@ -308,7 +308,7 @@ def test_wide_kernel_geometries(ctx, oracle, variant, distance):
     assert got[5, dup] == 0.0 and got[dup, 5] == 0.0
 
 
-@pytest.mark.parametrize("variant", [0, 20103, 20105, 20107, 20109, 20111, 20113])
+@pytest.mark.parametrize("variant", [0, 20103, 20105, 20107, 20109, 20111, 20113, 20203, 20207, 20213, 20403, 20405, 20409, 20413])
 @pytest.mark.parametrize("distance", ["hybrid", "exact"])
 def test_full_matrix_kernel(ctx, oracle, variant, distance):
     """dtw_full_matrix (column strips in passes, ONE DP for both ordered pairs): valid when the band never binds and the penalties
@@ -316,7 +316,9 @@ def test_full_matrix_kernel(ctx, oracle, variant, distance):
     rng = np.random.default_rng(variant + 7)
     # strips of 64 * CW columns: one pass for the short lengths, up to three for the long ones (the boundary column of a
     # pass goes through LDS), lengths on either side of a pass boundary
-    lens = [2, 3, 50, 64, 65, 130, 190, 191] if variant == 0 else [2, 3, 70, 193, 194, 333, 520, 571, 64 * (variant % 100) + 1, 64 * (variant % 100) + 2]
+    wcols = (64 // max((variant - 20000) // 100, 1)) * (variant % 100)   # columns per pass: G * CW
+    lens = [2, 3, 50, 64, 65, 130, 190, 191] if variant == 0 else [2, 3, 70, 193, 194, 333, 520, 571, wcols + 1, wcols + 2, 2 * wcols + 1]
+    lens = lens + [1, 17, 17, 18, 40, 40, 41, 75, 100]                   # 26 sequences: tiles whose waves hold several different pairs
     seqs = [np.cumsum(rng.standard_normal((n, 13)), axis=0).astype(np.float32) * 0.4 for n in lens]
     seqs.append(seqs[5].copy())
     frames = np.concatenate(seqs)
