@@ -430,7 +430,8 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
             for (auto &g : groups) if (g.first >= 20000) n_full += g.second.size();
             int global_key = 0;
             double global_cost = INFINITY;
-            for (int ppw = 1; ppw <= 4 && n_full > 0; ppw *= 2)
+            const int max_ppw = n_full * kSlotsPerTile < 8192 ? 1 : 4;   // too few pairs to fill the GPU: one wavefront each
+            for (int ppw = 1; ppw <= max_ppw && n_full > 0; ppw *= 2)
                 for (int cw = 5; cw <= max_strip_columns(batch->dim); cw += 2) {
                     const int k = 20000 + ppw * 100 + cw;
                     double total = 0.0;
