@@ -151,6 +151,14 @@ def test_single_pair_api_matches_oracle(ctx, oracle):
         want = oracle.dtw_pair(x, y, band, 0.8, 1.2, 1.0)
         assert_parity(np.array([a.score()]), np.array([want]))
     assert Alignment(ctx).score() == float("inf")       # Alignment::new().score(), alignments.rs:117-118
+    # long sequences, unit penalties: an explicit band that never binds (full-matrix kernel, several column passes, either
+    # orientation), one that binds beyond a wavefront (wide kernel), one within a wavefront (systolic)
+    for n, m, band in [(2600, 1900, 2600), (1900, 2600, 4000), (2000, 2100, 450), (1500, 1450, 120)]:
+        x = np.cumsum(rng.standard_normal((n, 10)), axis=0).astype(np.float32) * 0.3
+        y = np.cumsum(rng.standard_normal((m, 10)), axis=0).astype(np.float32) * 0.3
+        a = Alignment(ctx)
+        a.construct_alignment(x, y, AlignmentParams.default(band))
+        assert_parity(np.array([a.score()]), np.array([oracle.dtw_pair(x, y, band)]))
 
 
 def test_kat_through_the_gpu(ctx):
