@@ -107,6 +107,11 @@ extern "C" int apd_create(int device, apd_context **out)
     ctx->own_stream = true;
     hipEventCreate(&ctx->ev0);
     hipEventCreate(&ctx->ev1);
+    hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming);
+    for (int k = 0; k < apd_context::kSideStreams; ++k) {
+        hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking);
+        hipEventCreateWithFlags(&ctx->side_done[k], hipEventDisableTiming);
+    }
     *out = ctx;
     return APD_OK;
 }
@@ -121,6 +126,11 @@ extern "C" int apd_destroy(apd_context *ctx)
     if (ctx->ws_misc) hipFree(ctx->ws_misc);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->fork) hipEventDestroy(ctx->fork);
+    for (int k = 0; k < apd_context::kSideStreams; ++k) {
+        if (ctx->side[k]) { hipStreamSynchronize(ctx->side[k]); hipStreamDestroy(ctx->side[k]); }
+        if (ctx->side_done[k]) hipEventDestroy(ctx->side_done[k]);
+    }
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return APD_OK;
@@ -475,13 +485,30 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
     L.variant = ctx->variant;
     L.hybrid = ctx->distance_mode; L.tau = ctx->tau;
     if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    // Classes are independent (disjoint tiles, disjoint slab regions): with more than one, their launches are spread over
+    // side streams forked from and joined back into the context's stream, so that a class of a few tiles does not hold the
+    // GPU alone (a ragged banded corpus splits into a dozen geometries).
+    const bool fan_out = plan.classes.size() > 1 && ctx->side[0] != nullptr;
+    if (fan_out) {
+        HIP_TRY(ctx, hipEventRecord(ctx->fork, ctx->stream));
+        for (int k = 0; k < apd_context::kSideStreams; ++k) HIP_TRY(ctx, hipStreamWaitEvent(ctx->side[k], ctx->fork, 0));
+    }
+    int rc_launch = APD_OK;
+    size_t ci = 0;
     for (const apd_batch::TileClass &tc : plan.classes) {
         L.d_tiles = plan.d_tiles + tc.first; L.n_tiles = tc.count; L.w_max = tc.w_max;
         int status = APD_OK;
-        hipError_t e = launch_align(L, tc.geom_key, ctx->stream, ctx->last_error, &status);
-        if (e != hipSuccess) { ctx->last_error = std::string("launch_align: ") + hipGetErrorString(e); return APD_ERR_HIP; }
-        if (status != APD_OK) return status;
+        hipStream_t s = fan_out ? ctx->side[ci++ % apd_context::kSideStreams] : ctx->stream;
+        hipError_t e = launch_align(L, tc.geom_key, s, ctx->last_error, &status);
+        if (e != hipSuccess) { ctx->last_error = std::string("launch_align: ") + hipGetErrorString(e); rc_launch = APD_ERR_HIP; break; }
+        if (status != APD_OK) { rc_launch = status; break; }
     }
+    if (fan_out)                                                        // always join, also after a failed launch
+        for (int k = 0; k < apd_context::kSideStreams; ++k) {
+            HIP_TRY(ctx, hipEventRecord(ctx->side_done[k], ctx->side[k]));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done[k], 0));
+        }
+    if (rc_launch != APD_OK) return rc_launch;
     if (ctx->timing) { HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream)); ctx->timed = true; }
     return APD_OK;
 }

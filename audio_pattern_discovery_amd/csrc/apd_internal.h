@@ -92,6 +92,11 @@ struct apd_context {
     bool own_stream = false;
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // side streams for the launches of different tile classes (independent work, joined back into `stream` with events)
+    static constexpr int kSideStreams = 4;
+    hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t side_done[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr;
     bool timed = false;
     int variant = 0;
     int distance_mode = 1;            // 0 exact differences, 1 hybrid
