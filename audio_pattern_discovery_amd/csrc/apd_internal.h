@@ -37,6 +37,7 @@ struct AlignLaunch {
     BandSpec band;
     float *d_slab;               // [tiles of the rank][2][kTile][kTile]
     uint32_t w_max;              // upper bound of w over the pairs of this launch
+    uint32_t n_max;              // upper bound of the longer length over the pairs of this launch
     int variant;                 // 0 auto
     int hybrid;                  // 1: norm-expansion distances with exact recomputation below tau (see dtw_systolic.h)
     float tau;
@@ -58,6 +59,8 @@ int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen
 // >= 20000: full-matrix kernel, 20000 + (pairs per wavefront) * 100 + CW, for pairs of at most `rows` x `cols` frames (0 if it does not apply)
 int pick_full_key(uint32_t cols, uint32_t rows, uint32_t dim, int variant);   // (>= 10000: wide kernel, 10000 + NW * 100 + C)
 double full_key_cost(uint32_t cols, uint32_t rows, uint32_t dim, int key);    // modelled cost of one pair on that geometry (+inf: does not apply)
+// >= 30000: the same column strips with a binding band (two DPs): 30000 + (pairs per wavefront) * 100 + CW
+int pick_banded_strip_key(uint32_t cols, uint32_t rows, uint32_t dim, int variant);
 hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_off, const uint32_t *d_src_off, uint32_t n_seq,
                       uint64_t n_frames_padded, uint32_t src_dim, uint32_t dim, uint32_t dpad, hipStream_t stream);
 hipError_t launch_unpack(const float *d_gathered, float *d_out, const uint32_t *d_order, uint32_t n_seq, uint32_t world,
@@ -122,7 +125,7 @@ struct apd_batch {
     std::vector<uint64_t> offsets;    // frame offsets of the RESIDENT order (host)
     uint32_t min_len = 0, max_len = 0;
     // device-resident tile lists, grouped by the kernel geometry each tile needs
-    struct TileClass { int geom_key; uint32_t first, count, w_max; };
+    struct TileClass { int geom_key; uint32_t first, count, w_max, n_max; };
     struct TilePlan { uint4 *d_tiles = nullptr; std::vector<TileClass> classes; };
     mutable std::map<std::string, TilePlan> tile_cache;   // keyed by rank/world/band/variant
 };

@@ -171,12 +171,12 @@ extern template bool launch_wide<26>(const AlignLaunch &, int, int, hipStream_t,
 
 // Full-matrix kernel (dtw_full.h): column strips, one DP for both ordered pairs.
 template <int D>
-bool launch_full(const AlignLaunch &L, int nw, int cw, hipStream_t stream, hipError_t *err);
-extern template bool launch_full<8>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
-extern template bool launch_full<10>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
-extern template bool launch_full<13>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
-extern template bool launch_full<16>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
-extern template bool launch_full<20>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
-extern template bool launch_full<26>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
+bool launch_full(const AlignLaunch &L, bool banded, int ppw, int cw, hipStream_t stream, hipError_t *err);
+extern template bool launch_full<8>(const AlignLaunch &, bool, int, int, hipStream_t, hipError_t *);
+extern template bool launch_full<10>(const AlignLaunch &, bool, int, int, hipStream_t, hipError_t *);
+extern template bool launch_full<13>(const AlignLaunch &, bool, int, int, hipStream_t, hipError_t *);
+extern template bool launch_full<16>(const AlignLaunch &, bool, int, int, hipStream_t, hipError_t *);
+extern template bool launch_full<20>(const AlignLaunch &, bool, int, int, hipStream_t, hipError_t *);
+extern template bool launch_full<26>(const AlignLaunch &, bool, int, int, hipStream_t, hipError_t *);
 
 }  // namespace apd

@@ -25,7 +25,7 @@
 
 namespace apd {
 
-template <int D, int CW, int G, bool HYBRID>
+template <int D, int CW, int G, bool HYBRID, bool BANDED>
 __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
 {
     constexpr int DN = D + 1;
@@ -39,7 +39,9 @@ __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
     extern __shared__ float lds[];
     float *const xring = lds;                                     // [R][DP]
     const int lane = threadIdx.x, gl = lane % G;
-    float *const bound = xring + R * DP + (lane / G) * ((int)L.w_max + 4);   // [rows] per pair: D[i][last column of the previous pass] (w_max >= rows - 1)
+    // [rows] per pair and DP: D[i][last column of the previous pass]
+    float *const bound = xring + R * DP + (lane / G) * (BANDED ? 2 : 1) * ((int)L.n_max + 4);
+    float *const bound2 = bound + ((int)L.n_max + 4);
     constexpr uint32_t WPT = kSlotsPerTile / PPW;                 // wavefronts per tile
     const uint32_t tile = blockIdx.x / WPT, slot = (blockIdx.x % WPT) * PPW + lane / G;
     const PairInfo P = decode_pair(L, tile, slot);                // the pairs of a wave have the same a (slot / 16)
@@ -60,6 +62,10 @@ __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
     }
     float pen = L.band.mat, tau_thr = L.tau;
     asm volatile("" : "+v"(pen), "+v"(tau_thr));
+    // BANDED: the band binds.  Band offset u = j - i + w; score(a, b) lives on u in [0, 2w-1], score(b, a) -- the swapped
+    // pair's recurrence transposed, the same select for equal penalties -- on u in [1, 2w] (see dtw_generic.hip).  Cells
+    // outside get a local distance of +INF, which makes the node +INF whatever its predecessors are.
+    const int two_w = BANDED ? 2 * (sweep ? P.w : 2) : 0;
     const int jstar = m - 1;                                      // column of the result cell (n-1, m-1)
     const int pstar = (jstar - 1) / W, lstar = ((jstar - 1) % W) / CW, cstar = (jstar - 1) % CW;
     const int my_pass = sweep ? (m - 1 + W - 1) / W : 0;          // passes of this pair: columns 1 .. m-1
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
     for (int g = 0; g < PPW; ++g) n_pass = max(n_pass, __builtin_amdgcn_readlane(my_pass, g * G));
     const int tau_cap = (n - 1) + gl;
     const int total_r = (((n - 1) + G + U - 1) / U) * U;          // macro-steps 1 .. (n-1)+G-1 of a pass, rounded up
-    float res = 0.0f;
+    float res = 0.0f, res2 = 0.0f;
 
     const int fill_f = lane / LPF, fill_q = lane % LPF;
     auto fill_load = [&](int first_row, apd_f32x4 (&regs)[NFILL]) __attribute__((always_inline)) {
@@ -106,10 +112,11 @@ __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
         float yf[CW][DN];
 #pragma unroll
         for (int c = 0; c < CW; ++c) load_frame<DN>(yf[c], rsrc, b_off + (uint32_t)(min(j0 + c, m) - 1) * FB);
-        float prev[CW];
+        float prev[CW], prev2[CW];
 #pragma unroll
-        for (int c = 0; c < CW; ++c) prev[c] = APD_INF;
-        float diag = APD_INF, last = APD_INF;
+        for (int c = 0; c < CW; ++c) { prev[c] = APD_INF; prev2[c] = APD_INF; }
+        float diag = APD_INF, last = APD_INF, diag2 = APD_INF, last2 = APD_INF;
+        const int u_base = j0 + gl + (two_w >> 1);                // band offset of the lane's first cell at macro-step 0
 
         asm volatile("" ::: "memory");                            // the previous pass's ring reads stay above these writes
         for (int e = lane; e < G * DP; e += 64)                   // rows <= 0: sentinels
@@ -158,7 +165,28 @@ __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
                 // column of the previous pass (row tau; rows past n-1 are never used), column 0 does not exist in pass 0
                 const float edge = (pass > 0) ? bound[min(tau, n - 1)] : APD_INF;
                 const float left_in = group_from_lower<G>(last, edge, gl);
-                float left = left_in, mdiag = diag;
+                float left_in2 = APD_INF;
+                if (BANDED) {
+                    const float edge2 = (pass > 0) ? bound2[min(tau, n - 1)] : APD_INF;
+                    left_in2 = group_from_lower<G>(last2, edge2, gl);
+                }
+                float d2[CW];
+                if (BANDED) {
+                    // the lane's cells sit at offsets t .. t + CW - 1; only where a band edge crosses them is anything masked
+                    const int t = u_base - tau;
+                    const bool edge_here = (t < 1) | (t + CW - 1 > two_w - 1);
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) d2[c] = d[c];
+                    if (__ballot(edge_here) != 0ull) {
+#pragma unroll
+                        for (int c = 0; c < CW; ++c) {
+                            const unsigned u = (unsigned)(t + c);
+                            d2[c] = (u - 1u > (unsigned)(two_w - 1)) ? APD_INF : d[c];     // score(b, a): u in [1, 2w]
+                            d[c] = (u > (unsigned)(two_w - 1)) ? APD_INF : d[c];           // score(a, b): u in [0, 2w-1]
+                        }
+                    }
+                }
+                float left = left_in, mdiag = diag, left2 = left_in2, mdiag2 = diag2;
 #pragma unroll
                 for (int c = 0; c < CW; ++c) {
                     const float up = prev[c];
@@ -166,14 +194,26 @@ __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
                     mdiag = up;
                     prev[c] = r;
                     left = r;
+                    if (BANDED) {
+                        const float up2 = prev2[c];
+                        const float r2 = select_node<true>(left2, up2, mdiag2, d2[c], pen, pen, pen);
+                        mdiag2 = up2;
+                        prev2[c] = r2;
+                        left2 = r2;
+                    }
                 }
                 diag = left_in;                                   // (i, j0 - 1) is the MATCH input of (i + 1, j0)
-                if (tau == 0 && pass == 0) diag = (gl == 0) ? 0.0f : diag;   // lane 0 just swept row 0: D[0][0] = 0 is the MATCH input of cell (1, 1)
+                diag2 = left_in2;
+                if (tau == 0 && pass == 0) { diag = (gl == 0) ? 0.0f : diag; diag2 = (gl == 0) ? 0.0f : diag2; }   // lane 0 just swept row 0: D[0][0] = 0 is the MATCH input of cell (1, 1)
                 last = left;
-                if (more && gl == G - 1 && tau >= G - 1 && tau <= tau_cap) bound[tau - (G - 1)] = last;   // row tau - (G-1), read by lane 0 next pass
+                last2 = left2;
+                if (more && gl == G - 1 && tau >= G - 1 && tau <= tau_cap) {   // row tau - (G-1), read by lane 0 next pass
+                    bound[tau - (G - 1)] = last;
+                    if (BANDED) bound2[tau - (G - 1)] = last2;
+                }
                 if (pass == pstar && tau == tau_cap && gl == lstar) {
 #pragma unroll
-                    for (int c = 0; c < CW; ++c) if (c == cstar) res = prev[c];
+                    for (int c = 0; c < CW; ++c) if (c == cstar) { res = prev[c]; res2 = prev2[c]; }
                 }
             }
             fill_store(tau0 + U + 1, fill_regs);
@@ -181,40 +221,47 @@ __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
         }
     }
     if (sweep && gl == lstar) {
-        const float s = res / (float)(P.n + P.m);                 // alignments.rs:121
-        store_pair(L, tile, P, s, s);                             // score(a, b) == score(b, a)
+        const float denom = (float)(P.n + P.m);                   // alignments.rs:121
+        store_pair(L, tile, P, res / denom, (BANDED ? res2 : res) / denom);   // without a binding band score(a, b) == score(b, a)
     }
 }
 
-// L.w_max bounds the longer length of every pair of the launch: the boundary column (one float per row and pair) lives in LDS
-template <int D, int CW, int G>
+// L.n_max bounds the longer length of every pair of the launch: the boundary column (one float per row, pair and DP) lives in LDS
+template <int D, int CW, int G, bool BANDED>
 static hipError_t launch_full_c(const AlignLaunch &L, hipStream_t stream)
 {
     constexpr int DP = (D + 1 + 3) & ~3, R = (G == 64) ? 128 : 64, PPW = 64 / G;
-    const size_t lds_bytes = ((size_t)R * DP + (size_t)PPW * (L.w_max + 4) + 16) * sizeof(float);
+    const size_t lds_bytes = ((size_t)R * DP + (size_t)PPW * (BANDED ? 2 : 1) * (L.n_max + 4) + 16) * sizeof(float);
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;      // the dispatcher keeps such tiles off this kernel
     const dim3 grid(L.n_tiles * (kSlotsPerTile / PPW)), block(64);
     const bool hybrid = L.hybrid && D >= 10;
-    const void *fn = hybrid ? reinterpret_cast<const void *>(dtw_full_matrix<D, CW, G, true>) : reinterpret_cast<const void *>(dtw_full_matrix<D, CW, G, false>);
+    const void *fn = hybrid ? reinterpret_cast<const void *>(dtw_full_matrix<D, CW, G, true, BANDED>)
+                            : reinterpret_cast<const void *>(dtw_full_matrix<D, CW, G, false, BANDED>);
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    if (hybrid) hipLaunchKernelGGL((dtw_full_matrix<D, CW, G, true>), grid, block, lds_bytes, stream, L);
-    else hipLaunchKernelGGL((dtw_full_matrix<D, CW, G, false>), grid, block, lds_bytes, stream, L);
+    if (hybrid) hipLaunchKernelGGL((dtw_full_matrix<D, CW, G, true, BANDED>), grid, block, lds_bytes, stream, L);
+    else hipLaunchKernelGGL((dtw_full_matrix<D, CW, G, false, BANDED>), grid, block, lds_bytes, stream, L);
     return hipGetLastError();
 }
 
-// geometry key of the full-matrix kernel: 20000 + (pairs per wavefront = 64 / G) * 100 + CW
+// geometry key of the column-strip kernels: 20000 (band never binds, one DP) or 30000 (banded, two DPs)
+//                                          + (pairs per wavefront = 64 / G) * 100 + CW
 template <int D>
-bool launch_full(const AlignLaunch &L, int ppw, int cw, hipStream_t stream, hipError_t *err)
+bool launch_full(const AlignLaunch &L, bool banded, int ppw, int cw, hipStream_t stream, hipError_t *err)
 {
-#define APD_FCASE(CC) if constexpr (CC <= max_strip_columns(D)) { if (cw == CC) { \
-        if (ppw == 1) { *err = launch_full_c<D, CC, 64>(L, stream); return true; } \
-        if (ppw == 2) { *err = launch_full_c<D, CC, 32>(L, stream); return true; } \
-        if (ppw == 4) { *err = launch_full_c<D, CC, 16>(L, stream); return true; } } }
+#define APD_FCASE(CC) if constexpr (CC <= max_strip_columns(D)) { if (cw == CC && !banded) { \
+        if (ppw == 1) { *err = launch_full_c<D, CC, 64, false>(L, stream); return true; } \
+        if (ppw == 2) { *err = launch_full_c<D, CC, 32, false>(L, stream); return true; } \
+        if (ppw == 4) { *err = launch_full_c<D, CC, 16, false>(L, stream); return true; } } }
     APD_FCASE(3) APD_FCASE(5) APD_FCASE(7) APD_FCASE(9) APD_FCASE(11) APD_FCASE(13)
 #undef APD_FCASE
+#define APD_BCASE(CC) if constexpr (CC <= max_cells_per_lane(D)) { if (cw == CC && banded) { \
+        if (ppw == 1) { *err = launch_full_c<D, CC, 64, true>(L, stream); return true; } \
+        if (ppw == 4) { *err = launch_full_c<D, CC, 16, true>(L, stream); return true; } } }
+    APD_BCASE(5) APD_BCASE(9)
+#undef APD_BCASE
     return false;
 }
 

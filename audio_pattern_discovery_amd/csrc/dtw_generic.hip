@@ -242,10 +242,13 @@ int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen
 // (ppw * rows floats per wavefront) leave room for.  Returns +inf for a geometry that is not instantiated or does not fit.
 double full_key_cost(uint32_t cols, uint32_t rows, uint32_t dim, int key)
 {
-    const int ppw = (key - 20000) / 100, cw = key % 100;
-    if (key < 20000 || !(ppw == 1 || ppw == 2 || ppw == 4) || cw < 3 || cw > max_strip_columns(dim) || cw % 2 == 0) return INFINITY;
+    const bool banded = key >= 30000;
+    const int ppw = (key % 10000) / 100, cw = key % 100;
+    if (key < 20000 || key >= 40000) return INFINITY;
+    if (!banded && (!(ppw == 1 || ppw == 2 || ppw == 4) || cw < 3 || cw > max_strip_columns(dim) || cw % 2 == 0)) return INFINITY;
+    if (banded && (!(ppw == 1 || ppw == 4) || !(cw == 5 || cw == 9) || cw > max_cells_per_lane(dim))) return INFINITY;   // instantiated: dtw_full.h
     const uint32_t g = 64u / ppw;
-    const double lds_bytes = 4.0 * ((g == 64 ? 128.0 : 64.0) * ((dim + 4) & ~3u) + (double)ppw * (rows + 4) + 16);
+    const double lds_bytes = 4.0 * ((g == 64 ? 128.0 : 64.0) * ((dim + 4) & ~3u) + (double)ppw * (banded ? 2 : 1) * (rows + 4) + 16);
     if (lds_bytes > 160.0 * 1024) return INFINITY;
     const double waves_per_cu = std::floor(160.0 * 1024 / lds_bytes);
     const double lds_factor = waves_per_cu >= 8.0 ? 1.0 : 8.0 / waves_per_cu;
@@ -257,7 +260,7 @@ double full_key_cost(uint32_t cols, uint32_t rows, uint32_t dim, int key)
 
 int pick_full_key(uint32_t cols, uint32_t rows, uint32_t dim, int variant)
 {
-    if (variant != 0 && variant < 20000) return 0;                     // another kernel was requested
+    if (variant != 0 && (variant < 20000 || variant >= 30000)) return 0;   // another kernel was requested
     if (!is_kernel_dim(dim)) return 0;
     if (variant >= 20000) return std::isfinite(full_key_cost(cols, rows, dim, variant)) ? variant : 0;
     int best = 0;
@@ -266,6 +269,21 @@ int pick_full_key(uint32_t cols, uint32_t rows, uint32_t dim, int variant)
         for (int cw = 5; cw <= max_strip_columns(dim); cw += 2) {          // 3-column strips only on request: measured slower than the model says
             const double cost = full_key_cost(cols, rows, dim, 20000 + ppw * 100 + cw);
             if (cost < best_cost) { best = 20000 + ppw * 100 + cw; best_cost = cost; }
+        }
+    return best;
+}
+
+int pick_banded_strip_key(uint32_t cols, uint32_t rows, uint32_t dim, int variant)
+{
+    if (variant != 0 && (variant < 30000 || variant >= 40000)) return 0;
+    if (!is_kernel_dim(dim)) return 0;
+    if (variant >= 30000) return std::isfinite(full_key_cost(cols, rows, dim, variant)) ? variant : 0;
+    int best = 0;
+    double best_cost = INFINITY;
+    for (int ppw = 1; ppw <= 4; ppw *= 4)
+        for (int cw = 5; cw <= 9; cw += 4) {
+            const double cost = full_key_cost(cols, rows, dim, 30000 + ppw * 100 + cw);
+            if (cost < best_cost) { best = 30000 + ppw * 100 + cw; best_cost = cost; }
         }
     return best;
 }
@@ -302,15 +320,16 @@ static hipError_t launch_align_chunk(const AlignLaunch &L, int geom_key, hipStre
     AlignLaunch LL = L;
     if (LL.dim < 10) LL.hybrid = 0;            // the norm expansion saves D - 4 vector ops per cell: not worth its branch below D = 10
     if (geom_key >= 20000) {
-        const int nw = (geom_key - 20000) / 100, cw = geom_key % 100;
+        const bool banded = geom_key >= 30000;
+        const int nw = (geom_key % 10000) / 100, cw = geom_key % 100;
         hipError_t fe = hipSuccess;
         switch (L.dim) {
-            case 8: done = launch_full<8>(LL, nw, cw, stream, &fe); break;
-            case 10: done = launch_full<10>(LL, nw, cw, stream, &fe); break;
-            case 13: done = launch_full<13>(LL, nw, cw, stream, &fe); break;
-            case 16: done = launch_full<16>(LL, nw, cw, stream, &fe); break;
-            case 20: done = launch_full<20>(LL, nw, cw, stream, &fe); break;
-            case 26: done = launch_full<26>(LL, nw, cw, stream, &fe); break;
+            case 8: done = launch_full<8>(LL, banded, nw, cw, stream, &fe); break;
+            case 10: done = launch_full<10>(LL, banded, nw, cw, stream, &fe); break;
+            case 13: done = launch_full<13>(LL, banded, nw, cw, stream, &fe); break;
+            case 16: done = launch_full<16>(LL, banded, nw, cw, stream, &fe); break;
+            case 20: done = launch_full<20>(LL, banded, nw, cw, stream, &fe); break;
+            case 26: done = launch_full<26>(LL, banded, nw, cw, stream, &fe); break;
             default: break;
         }
         if (done && fe != hipSuccess) return fe;

@@ -4,5 +4,5 @@
 namespace apd {
 template bool launch_systolic<16>(const AlignLaunch &, int, int, bool, hipStream_t);
 template bool launch_wide<16>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
-template bool launch_full<16>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
+template bool launch_full<16>(const AlignLaunch &, bool, int, int, hipStream_t, hipError_t *);
 }
