@@ -424,7 +424,10 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
             if (fast_ok && uniform_pen && never_binds && (cols >= 49 || (ctx->variant >= 20000 && ctx->variant < 30000))) {
                 const int fk = pick_full_key(cols > 0 ? cols - 1 : 0, mx, batch->dim, ctx->variant);
                 if (fk != 0) key = fk;
-            } else if (fast_ok && uniform_pen && mx >= 3 && cols >= 49 && (2ull * w + 1 >= cols || ctx->variant >= 30000)) {
+            } else if (fast_ok && uniform_pen && mx >= 3 && cols >= 49 &&
+                       (2ull * w + 1 >= cols ||                                   // band at least as wide as the short side
+                        key == 0 ||                                               // no band-form kernel fits: anything beats the generic one
+                        ctx->variant >= 30000)) {
                 // the band binds, but is wider than the short side of the tile's pairs (w grows with |n - m|, alignments.rs:173):
                 // in band coordinates most offsets of such a pair lie outside it; column strips with masked band edges fit
                 const int bk = pick_banded_strip_key(cols - 1, mx, batch->dim, ctx->variant);
