@@ -395,8 +395,8 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
     char keybuf[160];
     uint32_t pct_bits;
     std::memcpy(&pct_bits, &band.pct, sizeof(pct_bits));
-    std::snprintf(keybuf, sizeof(keybuf), "%u/%u/%08x/%u/%d/%d/%d", rank, world, pct_bits, band.explicit_band, band.use_explicit,
-                  ctx->variant, (int)fast_ok);
+    std::snprintf(keybuf, sizeof(keybuf), "%u/%u/%08x/%u/%d/%d/%d/%d", rank, world, pct_bits, band.explicit_band, band.use_explicit,
+                  ctx->variant, (int)fast_ok, (int)uniform_pen);   // everything the choice of kernels depends on
     apd_batch::TilePlan &plan = batch->tile_cache[keybuf];
     if (!plan.d_tiles) {
         std::vector<uint2> tiles;

@@ -455,3 +455,19 @@ def test_banded_column_strips(ctx, oracle, variant, distance):
         assert np.array_equal(runs[0], runs[1])
         assert_parity(runs[0], want)
         assert runs[0][7, len(seqs) - 1] == 0.0
+
+
+def test_one_batch_many_configurations(ctx, oracle):
+    """The same resident batch aligned under different Discovery settings: the cached tile plans are keyed by everything
+    the kernel choice depends on (a plan made for equal penalties puts full-band tiles on the one-DP kernel, which is
+    wrong for unequal ones)."""
+    from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
+    from audio_pattern_discovery_amd.discovery import Discovery
+    frames, offsets = synth.make_sequences(30, 120, 13, seed=77, jitter=50)
+    w = AlignmentWorkers.new([NDSequence(s) for s in synth.split(frames, offsets)], ctx)
+    for pct, pens in [(1.0, (1.0, 1.0, 1.0)), (1.0, (0.5, 1.5, 1.0)), (0.1, (1.0, 1.0, 1.0)), (0.1, (2.0, 1.0, 0.5)), (1.0, (0.7, 0.7, 0.7)),
+                      (1.0, (1.0, 1.0, 1.0))]:
+        want = oracle.align_all(frames, offsets, pct, *pens, workers=8)
+        got = w.align_all(Discovery(warping_band_percentage=pct, insertion_penalty=pens[0], deletion_penalty=pens[1],
+                                    match_penalty=pens[2])).reshape(30, 30).copy()
+        assert_parity(got, want)
