@@ -379,6 +379,109 @@ static int check_lengths(const apd_batch *b)
     return APD_OK;
 }
 
+// Which kernel sweeps which tile.  Tiles are grouped by the kernel geometry their widest pair needs (w is bounded per tile
+// from the lengths of its 32 sequences), one launch per group: a few long or unequal sequences do not force every pair
+// onto a wide kernel.  The plan (device tile list + classes) is cached in the batch.
+static int build_tile_plan(apd_context *ctx, const apd_batch *batch, const BandSpec &band, uint32_t rank, uint32_t world,
+                           bool fast_ok, bool uniform_pen, apd_batch::TilePlan &plan)
+{
+    std::vector<uint2> tiles;
+    rank_tile_list(batch->n_seq, rank, world, tiles);
+    // per tile-row (16 sequences) min / max length
+    const uint32_t side = tiles_side(batch->n_seq);
+    std::vector<uint32_t> lo(side, 0xFFFFFFFFu), hi(side, 0);
+    for (uint32_t s = 0; s < batch->n_seq; ++s) {
+        const uint32_t len = (uint32_t)(batch->offsets[s + 1] - batch->offsets[s]);
+        lo[s / kTile] = std::min(lo[s / kTile], len);
+        hi[s / kTile] = std::max(hi[s / kTile], len);
+    }
+    std::map<int, std::vector<uint4>> groups;
+    std::map<int, uint32_t> wmax, nmax;
+    for (uint32_t t = 0; t < tiles.size(); ++t) {
+        const uint32_t mx = std::max(hi[tiles[t].x], hi[tiles[t].y]), mn = std::min(lo[tiles[t].x], lo[tiles[t].y]);
+        const uint32_t band_ub = band.use_explicit ? band.explicit_band : host_band_from_pct(band.pct, mx);
+        const uint32_t w = std::max(std::min(band_ub, mx), mx - mn) + 2;   // >= w of every pair of the tile
+        int key = fast_ok ? pick_geometry_key(2 * w + 1, batch->dim, ctx->variant, uniform_pen) : 0;
+        // the band binds nowhere in this tile (band >= longest - 3 for its longest sequence, hence for all) and the penalties
+        // are equal: both ordered scores are one number, swept over column strips (dtw_full.h).  Not for very short columns,
+        // where four pairs per wavefront in band form keep more lanes busy.
+        const uint32_t cols = std::min(hi[tiles[t].x], hi[tiles[t].y]);
+        const bool never_binds = mx >= 3 && std::min(band_ub, mx) >= mx - 3;
+        if (fast_ok && uniform_pen && never_binds && (cols >= 49 || (ctx->variant >= 20000 && ctx->variant < 30000))) {
+            const int fk = pick_full_key(cols > 0 ? cols - 1 : 0, mx, batch->dim, ctx->variant);
+            if (fk != 0) key = fk;
+        } else if (fast_ok && uniform_pen && mx >= 3 && cols >= 49 &&
+                   (2ull * w + 1 >= cols ||                                   // band at least as wide as the short side
+                    key == 0 ||                                               // no band-form kernel fits: anything beats the generic one
+                    ctx->variant >= 30000)) {
+            // the band binds, but is wider than the short side of the tile's pairs (w grows with |n - m|, alignments.rs:173):
+            // in band coordinates most offsets of such a pair lie outside it; column strips with masked band edges fit
+            const int bk = pick_banded_strip_key(cols - 1, mx, batch->dim, ctx->variant);
+            if (bk != 0) key = bk;
+        }
+        groups[key].push_back(make_uint4(tiles[t].x, tiles[t].y, t, 0));
+        wmax[key] = std::max(wmax[key], w);
+        nmax[key] = std::max(nmax[key], mx);
+    }
+    // Every class is a launch of its own, and launches of one stream do not overlap: a full-matrix class of a few dozen
+    // tiles would run at a fraction of the machine.  Small classes (all of them, in a small batch) move to the geometry
+    // that is best for the full-matrix tiles as a whole.
+    if (ctx->variant == 0) {
+        auto dims_of = [&](const uint4 &t, uint32_t *cols, uint32_t *rows) {
+            *rows = std::max(hi[t.x], hi[t.y]);
+            const uint32_t c = std::min(hi[t.x], hi[t.y]);
+            *cols = c > 0 ? c - 1 : 0;
+        };
+        for (int family = 20000; family <= 30000; family += 10000) {      // one DP (band never binds) / two DPs (banded)
+            auto in_family = [&](int k) { return k >= family && k < family + 10000; };
+            size_t n_fam = 0;
+            for (auto &g : groups) if (in_family(g.first)) n_fam += g.second.size();
+            if (n_fam == 0) continue;
+            const int max_ppw = n_fam * kSlotsPerTile < 8192 ? 1 : 4;    // too few pairs to fill the GPU: one wavefront each
+            int global_key = 0;
+            double global_cost = INFINITY;
+            for (int ppw = 1; ppw <= max_ppw; ppw *= 2)
+                for (int cw = 5; cw <= max_strip_columns(batch->dim); cw += 2) {
+                    const int k = family + ppw * 100 + cw;
+                    double total = 0.0;
+                    for (auto &g : groups) {
+                        if (!in_family(g.first)) continue;
+                        for (const uint4 &t : g.second) { uint32_t c, r; dims_of(t, &c, &r); total += full_key_cost(c, r, batch->dim, k); }
+                    }
+                    if (total < global_cost) { global_cost = total; global_key = k; }
+                }
+            const size_t min_class = n_fam < 2048 ? n_fam + 1 : 256;
+            if (global_key == 0) continue;
+            std::vector<int> small;
+            for (auto &g : groups) if (in_family(g.first) && g.first != global_key && g.second.size() < min_class) small.push_back(g.first);
+            for (int k : small) {
+                std::vector<uint4> &from = groups[k], &to = groups[global_key];
+                to.insert(to.end(), from.begin(), from.end());
+                wmax[global_key] = std::max(wmax[global_key], wmax[k]);
+                nmax[global_key] = std::max(nmax[global_key], nmax[k]);
+                groups.erase(k);
+                wmax.erase(k);
+                nmax.erase(k);
+            }
+            std::sort(groups[global_key].begin(), groups[global_key].end(), [](const uint4 &a, const uint4 &b) { return a.z < b.z; });
+        }
+    }
+    std::vector<uint4> flat;
+    for (auto &g : groups) {
+        plan.classes.push_back(apd_batch::TileClass{g.first, (uint32_t)flat.size(), (uint32_t)g.second.size(), wmax[g.first], nmax[g.first]});
+        flat.insert(flat.end(), g.second.begin(), g.second.end());
+    }
+    if (std::getenv("APD_DEBUG_PLAN"))                                  // tuning aid: which kernel geometry got how many tiles
+        for (const apd_batch::TileClass &tc : plan.classes)
+            std::fprintf(stderr, "[apd] rank %u/%u: geometry %d: %u tiles, w_max %u, n_max %u\n", rank, world, tc.geom_key, tc.count, tc.w_max, tc.n_max);
+    HIP_TRY(ctx, hipMalloc((void **)&plan.d_tiles, std::max<size_t>(flat.size(), 1) * sizeof(uint4)));
+    if (!flat.empty()) {
+        HIP_TRY(ctx, hipMemcpyAsync(plan.d_tiles, flat.data(), flat.size() * sizeof(uint4), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return APD_OK;
+}
+
 static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const BandSpec &band, uint32_t rank,
                             uint32_t world, float *d_slab)
 {
@@ -386,8 +489,6 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
     int rc = check_lengths(batch);
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // Tiles are grouped by the kernel geometry their widest pair needs (w is bounded per tile from the lengths of its
-    // 32 sequences), one launch per group: a few long or unequal sequences do not force every pair onto a wide kernel.
     const bool pens_ok = (band.ins > 0.0f) && (band.del > 0.0f) && (band.mat > 0.0f) && (band.ins < INFINITY) &&
                          (band.del < INFINITY) && (band.mat < INFINITY);   // the systolic kernel needs pen * INF = INF
     const bool fast_ok = pens_ok && batch->frames_bytes != 0;
@@ -399,100 +500,8 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
                   ctx->variant, (int)fast_ok, (int)uniform_pen);   // everything the choice of kernels depends on
     apd_batch::TilePlan &plan = batch->tile_cache[keybuf];
     if (!plan.d_tiles) {
-        std::vector<uint2> tiles;
-        rank_tile_list(batch->n_seq, rank, world, tiles);
-        // per tile-row (16 sequences) min / max length
-        const uint32_t side = tiles_side(batch->n_seq);
-        std::vector<uint32_t> lo(side, 0xFFFFFFFFu), hi(side, 0);
-        for (uint32_t s = 0; s < batch->n_seq; ++s) {
-            const uint32_t len = (uint32_t)(batch->offsets[s + 1] - batch->offsets[s]);
-            lo[s / kTile] = std::min(lo[s / kTile], len);
-            hi[s / kTile] = std::max(hi[s / kTile], len);
-        }
-        std::map<int, std::vector<uint4>> groups;
-        std::map<int, uint32_t> wmax, nmax;
-        for (uint32_t t = 0; t < tiles.size(); ++t) {
-            const uint32_t mx = std::max(hi[tiles[t].x], hi[tiles[t].y]), mn = std::min(lo[tiles[t].x], lo[tiles[t].y]);
-            const uint32_t band_ub = band.use_explicit ? band.explicit_band : host_band_from_pct(band.pct, mx);
-            const uint32_t w = std::max(std::min(band_ub, mx), mx - mn) + 2;   // >= w of every pair of the tile
-            int key = fast_ok ? pick_geometry_key(2 * w + 1, batch->dim, ctx->variant, uniform_pen) : 0;
-            // the band binds nowhere in this tile (band >= longest - 3 for its longest sequence, hence for all) and the penalties
-            // are equal: both ordered scores are one number, swept over column strips (dtw_full.h).  Not for very short columns,
-            // where four pairs per wavefront in band form keep more lanes busy.
-            const uint32_t cols = std::min(hi[tiles[t].x], hi[tiles[t].y]);
-            const bool never_binds = mx >= 3 && std::min(band_ub, mx) >= mx - 3;
-            if (fast_ok && uniform_pen && never_binds && (cols >= 49 || (ctx->variant >= 20000 && ctx->variant < 30000))) {
-                const int fk = pick_full_key(cols > 0 ? cols - 1 : 0, mx, batch->dim, ctx->variant);
-                if (fk != 0) key = fk;
-            } else if (fast_ok && uniform_pen && mx >= 3 && cols >= 49 &&
-                       (2ull * w + 1 >= cols ||                                   // band at least as wide as the short side
-                        key == 0 ||                                               // no band-form kernel fits: anything beats the generic one
-                        ctx->variant >= 30000)) {
-                // the band binds, but is wider than the short side of the tile's pairs (w grows with |n - m|, alignments.rs:173):
-                // in band coordinates most offsets of such a pair lie outside it; column strips with masked band edges fit
-                const int bk = pick_banded_strip_key(cols - 1, mx, batch->dim, ctx->variant);
-                if (bk != 0) key = bk;
-            }
-            groups[key].push_back(make_uint4(tiles[t].x, tiles[t].y, t, 0));
-            wmax[key] = std::max(wmax[key], w);
-            nmax[key] = std::max(nmax[key], mx);
-        }
-        // Every class is a launch of its own, and launches of one stream do not overlap: a full-matrix class of a few dozen
-        // tiles would run at a fraction of the machine.  Small classes (all of them, in a small batch) move to the geometry
-        // that is best for the full-matrix tiles as a whole.
-        if (ctx->variant == 0) {
-            auto dims_of = [&](const uint4 &t, uint32_t *cols, uint32_t *rows) {
-                *rows = std::max(hi[t.x], hi[t.y]);
-                const uint32_t c = std::min(hi[t.x], hi[t.y]);
-                *cols = c > 0 ? c - 1 : 0;
-            };
-            for (int family = 20000; family <= 30000; family += 10000) {      // one DP (band never binds) / two DPs (banded)
-                auto in_family = [&](int k) { return k >= family && k < family + 10000; };
-                size_t n_fam = 0;
-                for (auto &g : groups) if (in_family(g.first)) n_fam += g.second.size();
-                if (n_fam == 0) continue;
-                const int max_ppw = n_fam * kSlotsPerTile < 8192 ? 1 : 4;    // too few pairs to fill the GPU: one wavefront each
-                int global_key = 0;
-                double global_cost = INFINITY;
-                for (int ppw = 1; ppw <= max_ppw; ppw *= 2)
-                    for (int cw = 5; cw <= max_strip_columns(batch->dim); cw += 2) {
-                        const int k = family + ppw * 100 + cw;
-                        double total = 0.0;
-                        for (auto &g : groups) {
-                            if (!in_family(g.first)) continue;
-                            for (const uint4 &t : g.second) { uint32_t c, r; dims_of(t, &c, &r); total += full_key_cost(c, r, batch->dim, k); }
-                        }
-                        if (total < global_cost) { global_cost = total; global_key = k; }
-                    }
-                const size_t min_class = n_fam < 2048 ? n_fam + 1 : 256;
-                if (global_key == 0) continue;
-                std::vector<int> small;
-                for (auto &g : groups) if (in_family(g.first) && g.first != global_key && g.second.size() < min_class) small.push_back(g.first);
-                for (int k : small) {
-                    std::vector<uint4> &from = groups[k], &to = groups[global_key];
-                    to.insert(to.end(), from.begin(), from.end());
-                    wmax[global_key] = std::max(wmax[global_key], wmax[k]);
-                    nmax[global_key] = std::max(nmax[global_key], nmax[k]);
-                    groups.erase(k);
-                    wmax.erase(k);
-                    nmax.erase(k);
-                }
-                std::sort(groups[global_key].begin(), groups[global_key].end(), [](const uint4 &a, const uint4 &b) { return a.z < b.z; });
-            }
-        }
-        std::vector<uint4> flat;
-        for (auto &g : groups) {
-            plan.classes.push_back(apd_batch::TileClass{g.first, (uint32_t)flat.size(), (uint32_t)g.second.size(), wmax[g.first], nmax[g.first]});
-            flat.insert(flat.end(), g.second.begin(), g.second.end());
-        }
-        if (std::getenv("APD_DEBUG_PLAN"))                                  // tuning aid: which kernel geometry got how many tiles
-            for (const apd_batch::TileClass &tc : plan.classes)
-                std::fprintf(stderr, "[apd] rank %u/%u: geometry %d: %u tiles, w_max %u, n_max %u\n", rank, world, tc.geom_key, tc.count, tc.w_max, tc.n_max);
-        HIP_TRY(ctx, hipMalloc((void **)&plan.d_tiles, std::max<size_t>(flat.size(), 1) * sizeof(uint4)));
-        if (!flat.empty()) {
-            HIP_TRY(ctx, hipMemcpyAsync(plan.d_tiles, flat.data(), flat.size() * sizeof(uint4), hipMemcpyHostToDevice, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        }
+        rc = build_tile_plan(ctx, batch, band, rank, world, fast_ok, uniform_pen, plan);
+        if (rc) return rc;
     }
     AlignLaunch L{};
     L.d_frames = batch->d_frames; L.frames_bytes = batch->frames_bytes; L.d_seq_off = batch->d_seq_off;
