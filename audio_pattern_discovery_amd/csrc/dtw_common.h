@@ -87,7 +87,7 @@ __device__ __forceinline__ float select_node(float del_v, float ins_v, float m_v
         // m_v.  So base = (del_v == ins_v) ? m_v : min3(del_v, ins_v, m_v): 3 VALU ops, no scalar mask arithmetic.
         // (Identical to the branch chain for non-NaN inputs; NaN features are outside the supported domain.)
         const float lo = __builtin_fminf(__builtin_fminf(del_v, ins_v), m_v);
-        return ((del_v == ins_v) | force_match ? m_v : lo) + d;
+        return (((del_v == ins_v) | force_match) ? m_v : lo) + d;
     }
     const bool pick_d = (del_v < m_v) & (del_v < ins_v) & !force_match;
     const bool pick_i = (ins_v < m_v) & (ins_v < del_v) & !force_match;
