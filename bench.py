@@ -54,6 +54,8 @@ WORKLOADS["wide7"] = dict(n_seq=128, length=4000, dim=13, pct=0.1,
                           desc="128 seq len~4000 D=13, band=400: a binding band wider than one wavefront (dtw_fused_wide; not a BASELINE config)")
 WORKLOADS["wide11"] = dict(n_seq=128, length=3000, dim=13, pct=0.4,
                            desc="128 seq len~3000 D=13, band=1200: a binding band of 2400 offsets, 80 % of the sequence (banded strips vs 8-wave band form; not a BASELINE config)")
+WORKLOADS["short12"] = dict(n_seq=2048, length=220, jitter=70, dim=10, pct=0.1,
+                            desc="2048 short slices of 150..290 frames, D=10, band 10 % (w follows |n-m|): band-form kernels and banded strips mixed (not a BASELINE config)")
 WORKLOADS["rag10"] = dict(n_seq=512, length=525, jitter=375, dim=10, pct=0.1,
                           desc="512 ragged slices of 150..900 frames, D=10, band 10 %: w = max(band, |n-m|) + 2 spans every kernel family (not a BASELINE config)")
 WORKLOADS["short9"] = dict(n_seq=2048, length=220, jitter=70, dim=10, pct=1.0,
