@@ -22,7 +22,7 @@ print("== per-dispatch (kernel trace) of the alignment kernel ==")
 for path in find("trace/**/*kernel_trace.csv"):
     with open(path) as fp:
         for row in csv.DictReader(fp):
-            if "dtw_fused" in row.get("Kernel_Name", ""):
+            if "apd::dtw_" in row.get("Kernel_Name", ""):   # every alignment kernel: dtw_fused_systolic / _wide / _generic, dtw_full_matrix
                 dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
                 print("dur_ns=%d vgpr=%s sgpr=%s lds=%s scratch=%s grid=%s wg=%s %s" % (
                     dur, row.get("VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"), row.get("Scratch_Size"),
@@ -33,7 +33,7 @@ for d in find("pmc_*/"):
     for path in glob.glob(os.path.join(d, "**/*counter_collection.csv"), recursive=True):
         with open(path) as fp:
             for row in csv.DictReader(fp):
-                if "dtw_fused" in row.get("Kernel_Name", ""):
+                if "apd::dtw_" in row.get("Kernel_Name", ""):   # every alignment kernel: dtw_fused_systolic / _wide / _generic, dtw_full_matrix
                     sums[row["Counter_Name"]] += float(row["Counter_Value"])
                     n[row["Counter_Name"]] += 1
     for k in sorted(sums):
