@@ -410,7 +410,7 @@ static int build_tile_plan(apd_context *ctx, const apd_batch *batch, const BandS
         if (fast_ok && uniform_pen && never_binds && (cols >= 49 || (ctx->variant >= 20000 && ctx->variant < 30000))) {
             const int fk = pick_full_key(cols > 0 ? cols - 1 : 0, mx, batch->dim, ctx->variant);
             if (fk != 0) key = fk;
-        } else if (fast_ok && uniform_pen && mx >= 3 && cols >= 49 &&
+        } else if (fast_ok && mx >= 3 && cols >= 49 &&                          // (any penalties: unequal ones take the literal select)
                    (2ull * w + 1 >= cols ||                                   // band at least as wide as the short side
                     key == 0 ||                                               // no band-form kernel fits: anything beats the generic one
                     ctx->variant >= 30000)) {

@@ -25,7 +25,10 @@
 
 namespace apd {
 
-template <int D, int CW, int G, bool HYBRID, bool BANDED>
+// GENERAL_PEN (only with BANDED: unequal penalties make the two ordered scores differ even under a full band): the literal
+// comparison chain with DELETE / INSERT roles per DP and the reference's arithmetic operation for operation, as in the
+// systolic kernel's UNIFORM_PEN = false path -- bit-identical to the CPU code.
+template <int D, int CW, int G, bool HYBRID, bool BANDED, bool GENERAL_PEN = false>
 __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
 {
     constexpr int DN = D + 1;
@@ -60,8 +63,9 @@ __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
         m = __builtin_amdgcn_readfirstlane(m);
         b_off = __builtin_amdgcn_readfirstlane(b_off);
     }
-    float pen = L.band.mat, tau_thr = L.tau;
-    asm volatile("" : "+v"(pen), "+v"(tau_thr));
+    static_assert(!GENERAL_PEN || (BANDED && !HYBRID), "general penalties: two DPs on strict distances");
+    float pen = L.band.mat, tau_thr = L.tau, p_ins = L.band.ins, p_del = L.band.del;
+    asm volatile("" : "+v"(pen), "+v"(tau_thr), "+v"(p_ins), "+v"(p_del));
     // BANDED: the band binds.  Band offset u = j - i + w; score(a, b) lives on u in [0, 2w-1], score(b, a) -- the swapped
     // pair's recurrence transposed, the same select for equal penalties -- on u in [1, 2w] (see dtw_generic.hip).  Cells
     // outside get a local distance of +INF, which makes the node +INF whatever its predecessors are.
@@ -157,9 +161,9 @@ __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
                     for (int c = 0; c < CW; ++c) d[c] = __builtin_amdgcn_sqrtf(d[c]);
                 } else {
 #pragma unroll
-                    for (int c = 0; c < CW; ++c) d[c] = frame_dist<D, DN>(xs, yf[c]);
+                    for (int c = 0; c < CW; ++c) d[c] = GENERAL_PEN ? frame_dist_strict<D, DN>(xs, yf[c]) : frame_dist<D, DN>(xs, yf[c]);
                 }
-                weight_distances<CW>(d, pen);
+                if (!GENERAL_PEN) weight_distances<CW>(d, pen);
                 read_row(xs, tau + 1 - gl);                       // the row frame is dead: fetch the next one under the DP row
                 // DELETE input of the first column: last cell of the lane below (row i); lane 0 of a pair takes the boundary
                 // column of the previous pass (row tau; rows past n-1 are never used), column 0 does not exist in pass 0
@@ -190,13 +194,15 @@ __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
 #pragma unroll
                 for (int c = 0; c < CW; ++c) {
                     const float up = prev[c];
-                    const float r = select_node<true>(left, up, mdiag, d[c], pen, pen, pen);
+                    const float r = GENERAL_PEN ? select_node<false>(left, up, mdiag, d[c], p_del, p_ins, pen)     // score(a, b): left = DELETE, up = INSERT
+                                                : select_node<true>(left, up, mdiag, d[c], pen, pen, pen);
                     mdiag = up;
                     prev[c] = r;
                     left = r;
                     if (BANDED) {
                         const float up2 = prev2[c];
-                        const float r2 = select_node<true>(left2, up2, mdiag2, d2[c], pen, pen, pen);
+                        const float r2 = GENERAL_PEN ? select_node<false>(up2, left2, mdiag2, d2[c], p_del, p_ins, pen)   // score(b, a): up = DELETE, left = INSERT
+                                                     : select_node<true>(left2, up2, mdiag2, d2[c], pen, pen, pen);
                         mdiag2 = up2;
                         prev2[c] = r2;
                         left2 = r2;
@@ -227,6 +233,22 @@ __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
 }
 
 // L.n_max bounds the longer length of every pair of the launch: the boundary column (one float per row, pair and DP) lives in LDS
+template <int D, int CW, int G>
+static hipError_t launch_full_general(const AlignLaunch &L, hipStream_t stream)
+{
+    constexpr int DP = (D + 1 + 3) & ~3, R = (G == 64) ? 128 : 64, PPW = 64 / G;
+    const size_t lds_bytes = ((size_t)R * DP + (size_t)PPW * 2 * (L.n_max + 4) + 16) * sizeof(float);
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    const dim3 grid(L.n_tiles * (kSlotsPerTile / PPW)), block(64);
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_full_matrix<D, CW, G, false, true, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((dtw_full_matrix<D, CW, G, false, true, true>), grid, block, lds_bytes, stream, L);
+    return hipGetLastError();
+}
+
 template <int D, int CW, int G, bool BANDED>
 static hipError_t launch_full_c(const AlignLaunch &L, hipStream_t stream)
 {
@@ -257,9 +279,10 @@ bool launch_full(const AlignLaunch &L, bool banded, int ppw, int cw, hipStream_t
         if (ppw == 4) { *err = launch_full_c<D, CC, 16, false>(L, stream); return true; } } }
     APD_FCASE(3) APD_FCASE(5) APD_FCASE(7) APD_FCASE(9) APD_FCASE(11) APD_FCASE(13)
 #undef APD_FCASE
+    const bool general = !((L.band.ins == L.band.del) && (L.band.del == L.band.mat));   // unequal penalties: literal select, strict distances
 #define APD_BCASE(CC) if constexpr (CC <= max_cells_per_lane(D)) { if (cw == CC && banded) { \
-        if (ppw == 1) { *err = launch_full_c<D, CC, 64, true>(L, stream); return true; } \
-        if (ppw == 4) { *err = launch_full_c<D, CC, 16, true>(L, stream); return true; } } }
+        if (ppw == 1) { *err = general ? launch_full_general<D, CC, 64>(L, stream) : launch_full_c<D, CC, 64, true>(L, stream); return true; } \
+        if (ppw == 4) { *err = general ? launch_full_general<D, CC, 16>(L, stream) : launch_full_c<D, CC, 16, true>(L, stream); return true; } } }
     APD_BCASE(5) APD_BCASE(9)
 #undef APD_BCASE
     return false;
