@@ -116,11 +116,15 @@ extern "C" int apd_create(int device, apd_context **out)
     return APD_OK;
 }
 
+static void release_batch_device_memory(apd_batch *b);
+
 extern "C" int apd_destroy(apd_context *ctx)
 {
     if (!ctx) return APD_ERR_INVALID_ARG;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    for (apd_batch *b : ctx->batches) { release_batch_device_memory(b); b->ctx = nullptr; }   // orphans: see apd_batch_destroy
+    ctx->batches.clear();
     if (ctx->ws_tiles) hipFree(ctx->ws_tiles);
     if (ctx->ws_slab) hipFree(ctx->ws_slab);
     if (ctx->ws_misc) hipFree(ctx->ws_misc);
@@ -282,19 +286,31 @@ extern "C" int apd_batch_create(apd_context *ctx, const float *frames, const uin
         if (d_tmp) { hipStreamSynchronize(ctx->stream); hipFree(d_tmp); }
         if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return fail(APD_ERR_HIP); }
     }
+    ctx->batches.insert(b);
     *out = b;
     return APD_OK;
+}
+
+static void release_batch_device_memory(apd_batch *b)
+{
+    for (auto &kv : b->tile_cache) if (kv.second.d_tiles) hipFree(kv.second.d_tiles);
+    b->tile_cache.clear();
+    if (b->d_frames) hipFree(b->d_frames);
+    if (b->d_seq_off) hipFree(b->d_seq_off);
+    if (b->d_src_off) hipFree(b->d_src_off);
+    if (b->d_order) hipFree(b->d_order);
+    b->d_frames = nullptr; b->d_seq_off = nullptr; b->d_src_off = nullptr; b->d_order = nullptr;
 }
 
 extern "C" int apd_batch_destroy(apd_batch *b)
 {
     if (!b) return APD_ERR_INVALID_ARG;
-    if (b->ctx) { hipSetDevice(b->ctx->device); hipStreamSynchronize(b->ctx->stream); }
-    for (auto &kv : b->tile_cache) hipFree(kv.second.d_tiles);
-    if (b->d_frames) hipFree(b->d_frames);
-    if (b->d_seq_off) hipFree(b->d_seq_off);
-    if (b->d_src_off) hipFree(b->d_src_off);
-    if (b->d_order) hipFree(b->d_order);
+    if (b->ctx) {                                                        // else: orphaned by apd_destroy, device memory already released
+        hipSetDevice(b->ctx->device);
+        hipStreamSynchronize(b->ctx->stream);
+        release_batch_device_memory(b);
+        b->ctx->batches.erase(b);
+    }
     delete b;
     return APD_OK;
 }

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <map>
+#include <set>
 #include <string>
 #include <utility>
 #include <vector>
@@ -100,6 +101,9 @@ struct apd_context {
     hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t side_done[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr;
+    // batches created on this context and not yet destroyed: apd_destroy releases their device memory and orphans them, so
+    // that a later apd_batch_destroy (destruction order is the caller's, e.g. a garbage collector's) only frees the host part
+    std::set<apd_batch *> batches;
     bool timed = false;
     int variant = 0;
     int distance_mode = 1;            // 0 exact differences, 1 hybrid

@@ -471,3 +471,31 @@ def test_one_batch_many_configurations(ctx, oracle):
         got = w.align_all(Discovery(warping_band_percentage=pct, insertion_penalty=pens[0], deletion_penalty=pens[1],
                                     match_penalty=pens[2])).reshape(30, 30).copy()
         assert_parity(got, want)
+
+
+def test_very_long_sequences_and_the_length_limit(ctx, oracle):
+    """A 33 000-frame recording against short slices under a full band: column strips with a 132 KB boundary column in
+    LDS.  Beyond ~38 000 frames no kernel holds such a band (the strips keep one float per row in LDS, the generic kernel
+    its band offsets): the call reports an error instead of computing garbage, and the context stays usable.  Then the
+    destruction order the garbage collector may choose: context first, its batches afterwards."""
+    from audio_pattern_discovery_amd import _lib
+    from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
+    from audio_pattern_discovery_amd.discovery import Discovery
+    rng = np.random.default_rng(0)
+    arrs = [rng.standard_normal((n, 8)).astype(np.float32) for n in (33000, 120, 70)]
+    frames = np.concatenate(arrs)
+    offsets = np.concatenate([[0], np.cumsum([len(a) for a in arrs])]).astype(np.uint64)
+    got = AlignmentWorkers.new([NDSequence(a) for a in arrs], ctx).align_all(Discovery(warping_band_percentage=1.0)).reshape(3, 3)
+    assert_parity(got, oracle.align_all(frames, offsets, 1.0, workers=8))
+    too_long = [NDSequence(rng.standard_normal((n, 8)).astype(np.float32)) for n in (41000, 120)]
+    w = AlignmentWorkers.new(too_long, ctx)
+    with pytest.raises(Exception) as e:
+        w.align_all(Discovery(warping_band_percentage=1.0))
+    assert "band" in str(e.value).lower() or "wide" in str(e.value).lower()
+    ok = AlignmentWorkers.new([NDSequence(rng.standard_normal((n, 8)).astype(np.float32)) for n in (50, 60)], ctx)
+    assert np.isfinite(ok.align_all(Discovery(warping_band_percentage=1.0))).all()
+    # context destroyed before its batch: apd_destroy releases the batch's device memory, apd_batch_destroy the rest
+    c2 = _lib.Context(0)
+    w2 = AlignmentWorkers.new([NDSequence(a) for a in arrs[1:]], c2)
+    c2.close()
+    del w2
