@@ -69,6 +69,8 @@ typedef struct apd_cluster_op {
 
 /* ---- context ------------------------------------------------------------------------- */
 int apd_create(int device, apd_context **ctx);
+/* Also releases the device memory of every batch still alive on the context; such a batch may (and must, for its host
+ * part) still be passed to apd_batch_destroy afterwards, in any order, and is refused by every other call. */
 int apd_destroy(apd_context *ctx);
 /* Run on the caller's hipStream_t (e.g. torch's current stream) instead of the context's own. */
 int apd_set_stream(apd_context *ctx, void *hip_stream);
