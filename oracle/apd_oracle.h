@@ -9,7 +9,7 @@
  * vectors and no lock file, and no Rust toolchain exists in the build image, so
  * this oracle could be checked neither against reference fixtures nor against
  * reference outputs.  It is pinned only by (a) hand-derived known answers read
- * off the cited source lines (tests/test_oracle_kat.py) and (b) an independent
+ * off the cited source lines (tests/test_oracle.py) and (b) an independent
  * numpy re-derivation of the same recurrence (oracle/np_reference.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
