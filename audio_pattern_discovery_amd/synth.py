@@ -76,3 +76,37 @@ def make_audio(n_samples, seed=0):
         sig += rng.uniform(1000, 6000) * np.sin(phase + rng.uniform(0, 6.28))
     sig += 300.0 * rng.standard_normal(n_samples)
     return np.clip(np.rint(sig), -32768, 32767).astype(np.int16)
+
+
+def make_distance_matrix(n, kind="points", seed=0):
+    """A synthetic n x n distance matrix for the clustering leg (clustering.rs:81-110), zero diagonal, float32:
+
+    * "points": clustered points in 3-d with multiplicative directed noise (d[i][j] != d[j][i], as a binding band gives),
+    * "ties":   small integers -- exact linkage ties everywhere, asymmetric,
+    * "inf":    two blocks at +INF from each other (length-1 sequences score +INF, alignments.rs:122) plus one +INF row,
+    * "nan":    5 % NaN entries (percentile drops them, numerics.rs:127-130; a NaN linkage never wins),
+    * "uniform": i.i.d. U(0, 1)."""
+    rng = np.random.default_rng(seed)
+    if kind == "points":
+        centres = rng.standard_normal((max(n // 64, 4), 3)) * 4
+        pts = centres[rng.integers(0, len(centres), n)] + rng.standard_normal((n, 3)) * 0.3
+        d = np.zeros((n, n), dtype=np.float32)
+        for k in range(3):
+            d += (pts[:, None, k].astype(np.float32) - pts[None, :, k].astype(np.float32)) ** 2
+        d = np.sqrt(d) * (1.0 + 0.05 * rng.random((n, n), dtype=np.float32))
+    elif kind == "ties":
+        d = rng.integers(1, 7, size=(n, n)).astype(np.float32)
+    elif kind == "inf":
+        d = rng.random((n, n), dtype=np.float32) * 10
+        cut = max(n // 3, 1)
+        d[:cut, cut:] = np.inf
+        d[cut:, :cut] = np.inf
+        d[n // 2, :] = np.inf
+    elif kind == "nan":
+        d = rng.random((n, n), dtype=np.float32) * 10
+        d[rng.random((n, n)) < 0.05] = np.nan
+    else:
+        d = rng.random((n, n), dtype=np.float32)
+    d = np.ascontiguousarray(d, dtype=np.float32)
+    np.fill_diagonal(d, 0.0)
+    return d

@@ -411,6 +411,130 @@ int orc_clustering(const float *dist, uint32_t n, float perc, orc_cluster_op *op
     return 0;
 }
 
+/* ---------------------------------------------------- clustering, fast restatement
+ *
+ * Same merge sequence and the same linkage BITS as orc_clustering, in O(n^3) worst case instead of O(n^4):
+ * a linkage only changes when one of its two clusters is created, so linkage(p, q) (clustering.rs:153-170) is kept
+ * in a matrix and only the row and the column of the freshly merged cluster are recomputed -- by the reference's own
+ * loop order (x ascending over Cp, y ascending over Cq, ONE f32 accumulator, then / (size_x * size_y)), from sorted
+ * member lists.  The arg-min of merge() (clustering.rs:178-190: ascending cluster id for i, then j, strict '<') is
+ * the first minimum of the per-row first minima; a row's cached minimum is rescanned when its column merged away.
+ * tests/test_oracle.py proves it equal to the literal orc_clustering on hundreds of random / tied / infinite
+ * matrices; it exists so that the device UPGMA can be checked at sizes the O(n^4) loop cannot reach. */
+typedef struct { uint32_t *mem; uint32_t cnt; } fc_list;
+
+static float fc_linkage(const float *d, uint32_t n, const fc_list *cx, const fc_list *cy)   /* :153-170 */
+{
+    float distance = 0.0f;
+    for (uint32_t a = 0; a < cx->cnt; a++) {
+        const float *row = d + (uint64_t)cx->mem[a] * n;
+        for (uint32_t b = 0; b < cy->cnt; b++) distance = distance + row[cy->mem[b]];
+    }
+    float denom = (float)cx->cnt * (float)cy->cnt;                    /* size_x * size_y, counted in f32 (exact < 2^24) */
+    return distance / denom;
+}
+
+int orc_clustering_fast(const float *dist, uint32_t n, float perc, orc_cluster_op *ops,
+                        uint32_t *n_ops, uint32_t *roots, uint32_t *n_roots, float *threshold_out)
+{
+    float threshold;
+    if (orc_percentile(dist, (uint64_t)n * n, perc, &threshold) != 0) return -1;   /* :101 */
+    if (threshold_out) *threshold_out = threshold;
+    const uint64_t nn = (uint64_t)n * n;
+    float *L = (float *)malloc(sizeof(float) * (nn ? nn : 1));        /* L[sp*n+sq]: linkage of the clusters in slots sp, sq */
+    fc_list *lists = (fc_list *)calloc(n ? n : 1, sizeof(fc_list));   /* sorted members of the cluster in a slot */
+    uint32_t *slot_id = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    uint32_t *active = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));   /* live slots in ascending cluster id */
+    float *best_v = (float *)malloc(sizeof(float) * (n ? n : 1));
+    uint32_t *best_c = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    uint8_t *stale = (uint8_t *)malloc(n ? n : 1);
+    uint64_t *parents = (uint64_t *)malloc(sizeof(uint64_t) * (2 * (uint64_t)n + 2));
+    for (uint32_t i = 0; i < n; i++) {
+        lists[i].mem = (uint32_t *)malloc(sizeof(uint32_t)); lists[i].mem[0] = i; lists[i].cnt = 1;
+        slot_id[i] = i; active[i] = i; stale[i] = 1; parents[i] = i;
+    }
+    for (uint64_t e = 0; e < nn; e++) { float s = 0.0f; s = s + dist[e]; L[e] = s / (1.0f * 1.0f); }
+    uint32_t n_act = n, cnt = 0;
+    uint64_t n_par = n;
+    float distance = 0.0f;                                            /* :103 */
+    while (n_act > 1 && distance < threshold) {                       /* :104 (n_clusters == n_act until a degenerate merge ends the loop) */
+        #pragma omp parallel for schedule(dynamic, 16)
+        for (uint32_t a = 0; a < n_act; a++) {
+            const uint32_t sp = active[a];
+            if (!stale[sp]) continue;
+            float bv = ORC_INF; uint32_t bc = UINT32_MAX;
+            for (uint32_t b = 0; b < n_act; b++) {
+                const uint32_t sq = active[b];
+                if (sq == sp) continue;                               /* :182 */
+                const float l = L[(uint64_t)sp * n + sq];
+                if (l < bv) { bv = l; bc = sq; }
+            }
+            best_v[sp] = bv; best_c[sp] = bc; stale[sp] = 0;
+        }
+        float min_linkage = ORC_INF;                                  /* :178 */
+        uint32_t wp = UINT32_MAX, wq = UINT32_MAX;
+        for (uint32_t a = 0; a < n_act; a++) {
+            const uint32_t sp = active[a];
+            if (best_c[sp] != UINT32_MAX && best_v[sp] < min_linkage) { min_linkage = best_v[sp]; wp = sp; wq = best_c[sp]; }
+        }
+        const uint64_t k = n_par;                                     /* :135 */
+        if (wp == UINT32_MAX) {
+            /* no linkage below +INF: min_merge stays (0, 0) (:179) and is merged: instance 0 is re-parented */
+            parents[0] = k; parents[n_par++] = k;
+            ops[cnt].merge_i = 0; ops[cnt].merge_j = 0; ops[cnt].into = (uint32_t)k;
+            ops[cnt].distance = min_linkage; ops[cnt].operation = ORC_S2S;
+            cnt++;
+            distance = min_linkage;                                   /* INF < threshold is false: the loop ends */
+            break;
+        }
+        const uint64_t p = slot_id[wp], q = slot_id[wq];
+        parents[p] = k; parents[q] = k; parents[n_par++] = k;         /* :136-139 */
+        uint32_t op;                                                  /* :193-201 */
+        if (p < n && q < n) op = ORC_S2S;
+        else if (p >= n && q >= n) op = ORC_C2C;
+        else if (p >= n && q < n) op = ORC_C2S;
+        else op = ORC_S2C;
+        ops[cnt].merge_i = (uint32_t)p; ops[cnt].merge_j = (uint32_t)q; ops[cnt].into = (uint32_t)k;
+        ops[cnt].distance = min_linkage; ops[cnt].operation = op;
+        cnt++;
+        distance = min_linkage;                                       /* :106 */
+        /* the new cluster lives in slot wp: merged sorted member list */
+        fc_list *lp = &lists[wp], *lq = &lists[wq];
+        uint32_t *mm = (uint32_t *)malloc(sizeof(uint32_t) * (lp->cnt + lq->cnt));
+        uint32_t ia = 0, ib = 0, io = 0;
+        while (ia < lp->cnt && ib < lq->cnt) mm[io++] = (lp->mem[ia] < lq->mem[ib]) ? lp->mem[ia++] : lq->mem[ib++];
+        while (ia < lp->cnt) mm[io++] = lp->mem[ia++];
+        while (ib < lq->cnt) mm[io++] = lq->mem[ib++];
+        free(lp->mem); free(lq->mem);
+        lp->mem = mm; lp->cnt = io; lq->mem = NULL; lq->cnt = 0;
+        slot_id[wp] = (uint32_t)k;
+        uint32_t w = 0;                                               /* id order: drop p and q, append k (the largest id) */
+        for (uint32_t a = 0; a < n_act; a++) if (active[a] != wp && active[a] != wq) active[w++] = active[a];
+        active[w++] = wp;
+        n_act = w;
+        #pragma omp parallel for schedule(dynamic, 4)
+        for (uint32_t a = 0; a < n_act - 1; a++) {
+            const uint32_t s = active[a];
+            L[(uint64_t)wp * n + s] = fc_linkage(dist, n, &lists[wp], &lists[s]);
+            const float lrk = fc_linkage(dist, n, &lists[s], &lists[wp]);
+            L[(uint64_t)s * n + wp] = lrk;
+            if (best_c[s] == wp || best_c[s] == wq) stale[s] = 1;
+            else if (lrk < best_v[s]) { best_v[s] = lrk; best_c[s] = wp; }   /* k is last in id order: strict '<' */
+        }
+        stale[wp] = 1;
+    }
+    /* clusters() (:109, :146-148): the distinct roots, ascending */
+    uint64_t *rt = (uint64_t *)malloc(sizeof(uint64_t) * (n ? n : 1));
+    for (uint32_t i = 0; i < n; i++) { uint64_t r = i; while (r != parents[r]) r = parents[r]; rt[i] = r; }
+    qsort(rt, n, sizeof(uint64_t), cmp_u64);
+    uint32_t nc = 0;
+    for (uint32_t i = 0; i < n; i++) if (i == 0 || rt[i] != rt[i - 1]) roots[nc++] = (uint32_t)rt[i];
+    *n_roots = nc; *n_ops = cnt;
+    for (uint32_t i = 0; i < n; i++) free(lists[i].mem);
+    free(rt); free(L); free(lists); free(slot_id); free(active); free(best_v); free(best_c); free(stale); free(parents);
+    return 0;
+}
+
 /* clustering.rs:40-76 */
 int orc_cluster_sets(const orc_cluster_op *ops, uint32_t n_ops, const uint32_t *roots,
                      uint32_t n_roots, uint32_t n, uint32_t *members, uint32_t *set_off,

@@ -83,6 +83,13 @@ typedef struct {
 int orc_clustering(const float *dist, uint32_t n, float perc, orc_cluster_op *ops,
                    uint32_t *n_ops, uint32_t *roots, uint32_t *n_roots, float *threshold);
 
+/* clustering.rs:81-210 -- the same function as orc_clustering (same ops, same linkage bits, same roots), O(n^3)
+ * worst case: linkages are cached per cluster pair and only the merged cluster's row and column are re-summed, in the
+ * reference's own order.  Proven equal to the literal loop in tests/test_oracle.py; used to check the device UPGMA at
+ * N in the thousands, where the literal O(n^4) loop cannot go.  OpenMP over independent linkages. */
+int orc_clustering_fast(const float *dist, uint32_t n, float perc, orc_cluster_op *ops,
+                        uint32_t *n_ops, uint32_t *roots, uint32_t *n_roots, float *threshold);
+
 /* clustering.rs:40-76 -- cluster_sets: members[] receives the concatenated leaf lists
  * (in the reference's replay order), set_off[n_sets+1] the boundaries; roots never
  * merged are omitted.  Roots are taken in the order given. */

@@ -62,6 +62,8 @@ def lib():
     L.orc_percentile.argtypes = [f32p, C.c_uint64, C.c_float, f32p]
     L.orc_clustering.restype = C.c_int
     L.orc_clustering.argtypes = [f32p, C.c_uint32, C.c_float, C.POINTER(OrcOp), u32p, u32p, u32p, f32p]
+    L.orc_clustering_fast.restype = C.c_int
+    L.orc_clustering_fast.argtypes = L.orc_clustering.argtypes
     L.orc_cluster_sets.restype = C.c_int
     L.orc_cluster_sets.argtypes = [C.POINTER(OrcOp), C.c_uint32, u32p, C.c_uint32, C.c_uint32,
                                    u32p, u32p, u32p]
@@ -142,15 +144,16 @@ def percentile(x, perc):
     return float(v.value)
 
 
-def clustering(dist, n, perc):
-    """AgglomerativeClustering::clustering (clustering.rs:81-110), literal.
-    Returns (ops list of dicts, sorted root ids, threshold)."""
+def clustering(dist, n, perc, fast=False):
+    """AgglomerativeClustering::clustering (clustering.rs:81-110): the literal O(n^4) loop, or (fast=True) the cached-linkage
+    restatement that tests/test_oracle.py proves equal to it.  Returns (ops list of dicts, sorted root ids, threshold)."""
     dist = _f32(dist).ravel()
     ops = (OrcOp * max(n, 1))()
     roots = np.zeros(max(n, 1), dtype=np.uint32)
     n_ops, n_roots, thr = C.c_uint32(0), C.c_uint32(0), C.c_float(0)
-    rc = lib().orc_clustering(_p(dist, C.c_float), n, float(perc), ops, C.byref(n_ops),
-                              _p(roots, C.c_uint32), C.byref(n_roots), C.byref(thr))
+    fn = lib().orc_clustering_fast if fast else lib().orc_clustering
+    rc = fn(_p(dist, C.c_float), n, float(perc), ops, C.byref(n_ops),
+            _p(roots, C.c_uint32), C.byref(n_roots), C.byref(thr))
     if rc != 0:
         raise IndexError("clustering: percentile index out of range (the reference panics here)")
     out = [dict(merge_i=o.merge_i, merge_j=o.merge_j, into=o.into, distance=o.distance,

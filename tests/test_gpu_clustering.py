@@ -131,3 +131,30 @@ def test_end_to_end_align_then_cluster(ctx, oracle):
     want_ops, want_roots, _ = oracle.clustering(d, 48, 0.05)
     check_ops(ops, want_ops, 48)
     assert sorted(roots) == want_roots
+
+
+@pytest.mark.parametrize("n,kind,perc", [(300, "points", 0.05), (300, "ties", 0.6), (700, "nan", 0.5), (1100, "points", 0.05),
+                                         (1100, "inf", 0.9), (1500, "ties", 0.4), (2048, "points", 0.05), (4096, "points", 0.05),
+                                         (4500, "uniform", 0.02), (4500, "ties", 0.5)])
+def test_large_matrices_match_fast_oracle(ctx, oracle, n, kind, perc):
+    """Device UPGMA at sizes the literal O(n^4) oracle cannot reach (row-minimum loops beyond one workgroup's width, the
+    arg-min over more than 1024 rows, grid-stride rows beyond 4096, long exact-order chains), against the cached-linkage
+    CPU oracle that tests/test_oracle.py proves equal to the literal one.  Merge sequence (merge_i, merge_j, into, kind),
+    roots and threshold identical; linkages bit for bit (the tolerance asked is 1e-5)."""
+    from audio_pattern_discovery_amd.clustering import AgglomerativeClustering
+    d = synth.make_distance_matrix(n, kind, seed=n + len(kind))
+    want_ops, want_roots, want_thr = oracle.clustering(d, n, perc, fast=True)
+    ops, roots, thr = AgglomerativeClustering.clustering(d, n, perc, ctx, return_threshold=True)
+    assert thr == want_thr
+    assert len(ops) == len(want_ops)
+    got = np.array([(o.merge_i, o.merge_j, o.into, int(o.operation)) for o in ops], dtype=np.int64).reshape(-1, 4)
+    names = {"Sequence2Sequence": 0, "Sequence2Cluster": 1, "Cluster2Sequence": 2, "Cluster2Cluster": 3}
+    want = np.array([(o["merge_i"], o["merge_j"], o["into"], names[o["operation"]]) for o in want_ops], dtype=np.int64).reshape(-1, 4)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, "first differing merge %d: got %s want %s" % (bad[0], got[bad[0]], want[bad[0]])
+    gd = np.array([o.distance for o in ops], dtype=np.float32)
+    wd = np.array([o["distance"] for o in want_ops], dtype=np.float32)
+    assert np.array_equal(gd.view(np.uint32), wd.view(np.uint32)), "linkage bits differ"
+    assert sorted(roots) == want_roots
+    if kind == "points":
+        assert len(ops) > n // 2                                     # the run really went deep into the dendrogram

@@ -175,3 +175,54 @@ def test_companion_oracles_definitions(oracle):
     conv = np.array([tri @ mag[p - 14:p] for p in range(14, 128, 7)])
     ce = 0.5 * sf.dct(np.log(conv + 1e-6), type=1)[4:]
     np.testing.assert_allclose(c[1], ce - ce.mean(), rtol=0, atol=2e-4)
+
+
+# ---- the fast clustering oracle equals the literal one (it is what checks the device UPGMA at N in the thousands)
+
+def _random_distance_matrix(rng, n, kind):
+    if kind == "points":                                   # clustered points, directed noise (the band makes d[i][j] != d[j][i])
+        centres = rng.standard_normal((max(n // 6, 1), 3)) * 4
+        pts = centres[rng.integers(0, len(centres), n)] + rng.standard_normal((n, 3)) * rng.choice([0.05, 0.5, 2.0])
+        d = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1))
+        d = d * (1.0 + 0.05 * rng.random((n, n)))
+    elif kind == "ties":                                   # small integers: exact ties everywhere, asymmetric
+        d = rng.integers(1, rng.integers(3, 9), size=(n, n)).astype(np.float64)
+    elif kind == "inf":                                    # blocks that cannot reach each other (length-1 sequences give +INF)
+        d = rng.random((n, n)) * 10
+        cut = rng.integers(1, n) if n > 1 else 0
+        d[:cut, cut:] = np.inf
+        d[cut:, :cut] = np.inf
+        if rng.random() < 0.3:
+            d[rng.integers(0, n), :] = np.inf
+    elif kind == "nan":
+        d = rng.random((n, n)) * 10
+        d[rng.random((n, n)) < 0.05] = np.nan
+    else:                                                  # plain uniform
+        d = rng.random((n, n))
+    d = d.astype(np.float32)
+    np.fill_diagonal(d, 0.0)
+    return d
+
+
+def test_fast_clustering_oracle_equals_literal_oracle(oracle):
+    rng = np.random.default_rng(20261004)
+    kinds = ["points", "ties", "inf", "nan", "uniform"]
+    cases = 0
+    for rep in range(220):
+        n = int(rng.integers(1, 72)) if rep < 212 else 256
+        kind = kinds[rep % len(kinds)] if rep < 212 else kinds[rep % 3]
+        d = _random_distance_matrix(rng, n, kind)
+        perc = float(rng.choice([0.0, 0.05, 0.3, 0.6, 0.9, 0.97]))
+        try:
+            want = oracle.clustering(d, n, perc)
+        except IndexError:
+            with pytest.raises(IndexError):
+                oracle.clustering(d, n, perc, fast=True)
+            continue
+        got = oracle.clustering(d, n, perc, fast=True)
+        assert len(got[0]) == len(want[0])
+        for g, w in zip(got[0], want[0]):                  # every field, the linkage bit for bit (NaN never appears in an op)
+            assert g == w, (rep, n, kind, perc, g, w)
+        assert got[1] == want[1] and (got[2] == want[2] or (np.isnan(got[2]) and np.isnan(want[2])))
+        cases += 1
+    assert cases >= 200
