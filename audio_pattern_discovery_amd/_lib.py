@@ -19,6 +19,9 @@ APD_ERR_EMPTY_SEQUENCE = -5
 APD_ERR_BAND_TOO_WIDE = -6
 APD_ERR_INDEX = -7
 APD_ERR_UNSUPPORTED = -8
+APD_ERR_INCOMPLETE = -9
+APD_ERR_COMM = -10
+APD_COMM_ID_BYTES = 128
 
 
 class AlignConfig(C.Structure):
@@ -64,6 +67,18 @@ SYMBOLS = [
     ("apd_set_variant", C.c_int, [_vp, C.c_int]),
     ("apd_set_distance_mode", C.c_int, [_vp, C.c_int, C.c_float]),
     ("apd_selftest", C.c_int, [_vp]),
+    ("apd_set_fault_injection", C.c_int, [_vp, C.c_uint32]),
+    ("apd_batch_refill", C.c_int, [_vp, _vp, _vp, C.c_int]),
+    ("apd_batch_nonfinite", C.c_int, [_vp, _vp, C.POINTER(C.c_int)]),
+    ("apd_comm_unique_id", C.c_int, [_vp]),
+    ("apd_comm_create", C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
+    ("apd_comm_destroy", C.c_int, [_vp]),
+    ("apd_comm_count", C.c_int, [_vp, _u32p]),
+    ("apd_comm_rank", C.c_int, [_vp, _u32p]),
+    ("apd_align_all_sharded_async", C.c_int, [_vp, _vp, _vp, C.POINTER(AlignConfig), _vp]),
+    ("apd_all_gather_async", C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64]),
+    ("apd_align_all_multi", C.c_int, [C.POINTER(C.c_int), C.c_uint32, _f32p, _u64p, C.c_uint32, C.c_uint32,
+                                      C.POINTER(AlignConfig), _f32p, _u32p]),
     ("apd_discovery_alignment_params", C.c_int, [C.POINTER(AlignConfig), C.c_uint64, C.POINTER(AlignmentParamsC)]),
     ("apd_batch_create", C.c_int, [_vp, _vp, _u64p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_vp)]),
     ("apd_batch_destroy", C.c_int, [_vp]),
@@ -119,7 +134,7 @@ def lib():
 def check(status, ctx_handle=None):
     if status != APD_OK:
         detail = ""
-        if ctx_handle is not None and status == APD_ERR_HIP:
+        if ctx_handle is not None and status in (APD_ERR_HIP, APD_ERR_INCOMPLETE, APD_ERR_COMM):
             detail = lib().apd_last_error(ctx_handle).decode()
         raise ApdError(status, detail)
 
@@ -163,6 +178,10 @@ class Context:
 
     def selftest(self):
         check(lib().apd_selftest(self.handle), self.handle)
+
+    def set_fault_injection(self, drop_tiles):
+        """TEST HOOK: the next alignment launches skip the last `drop_tiles` tiles of every kernel class."""
+        check(lib().apd_set_fault_injection(self.handle, int(drop_tiles)))
 
 
 _default_ctx = None

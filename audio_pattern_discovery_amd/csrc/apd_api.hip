@@ -84,6 +84,8 @@ extern "C" const char *apd_status_string(int s)
         case APD_ERR_BAND_TOO_WIDE: return "warping band too wide for one wavefront";
         case APD_ERR_INDEX: return "percentile index out of range (the reference panics, numerics.rs:132)";
         case APD_ERR_UNSUPPORTED: return "unsupported";
+        case APD_ERR_INCOMPLETE: return "a pair score was never written (launch cut short or skipped): NaN left in the output";
+        case APD_ERR_COMM: return "RCCL error";
         default: return "unknown status";
     }
 }
@@ -105,6 +107,11 @@ extern "C" int apd_create(int device, apd_context **out)
         return APD_ERR_HIP;
     }
     ctx->own_stream = true;
+    if (hipMalloc((void **)&ctx->d_status, 64) != hipSuccess || hipMemset(ctx->d_status, 0, 64) != hipSuccess) {
+        hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return APD_ERR_OOM;
+    }
     hipEventCreate(&ctx->ev0);
     hipEventCreate(&ctx->ev1);
     hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming);
@@ -128,6 +135,8 @@ extern "C" int apd_destroy(apd_context *ctx)
     if (ctx->ws_tiles) hipFree(ctx->ws_tiles);
     if (ctx->ws_slab) hipFree(ctx->ws_slab);
     if (ctx->ws_misc) hipFree(ctx->ws_misc);
+    if (ctx->ws_gather) hipFree(ctx->ws_gather);
+    if (ctx->d_status) hipFree(ctx->d_status);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->fork) hipEventDestroy(ctx->fork);
@@ -149,11 +158,31 @@ extern "C" int apd_set_stream(apd_context *ctx, void *hip_stream)
     return APD_OK;
 }
 
+// Waits for the stream and reads the sticky device status word back; a raised bit is reported once and cleared.
+static int sync_and_report(apd_context *ctx)
+{
+    uint32_t st = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&st, ctx->d_status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (st & 1u) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(st), ctx->stream));
+        ctx->last_error = "unpack met a pair score that no alignment kernel wrote (NaN poison survived): launch cut short or skipped";
+        return APD_ERR_INCOMPLETE;
+    }
+    return APD_OK;
+}
+
 extern "C" int apd_synchronize(apd_context *ctx)
 {
     if (!ctx) return APD_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return sync_and_report(ctx);
+}
+
+extern "C" int apd_set_fault_injection(apd_context *ctx, uint32_t drop_tiles)
+{
+    if (!ctx) return APD_ERR_INVALID_ARG;
+    ctx->drop_tiles = drop_tiles;
     return APD_OK;
 }
 
@@ -250,10 +279,14 @@ extern "C" int apd_batch_create(apd_context *ctx, const float *frames, const uin
     // one kernel geometry fits the whole tile -- and the most expensive tiles of a launch start first.
     length_order(offsets, n_seq, b->order);
     b->offsets.assign(n_seq + 1, 0);                                     // offsets of the RESIDENT order
-    std::vector<uint32_t> off32(n_seq + 1), src32(n_seq + 1, 0);
+    // device metadata, one allocation and one copy: [seq_off | src_off | order | flags]
+    const size_t m1 = (size_t)n_seq + 1;
+    b->h_meta.assign(3 * m1 + 4, 0u);
+    uint32_t *off32 = b->h_meta.data(), *src32 = off32 + m1, *ord32 = src32 + m1;
     for (uint32_t p = 0; p < n_seq; ++p) {
         b->offsets[p + 1] = b->offsets[p] + (offsets[b->order[p] + 1] - offsets[b->order[p]]);
         src32[p] = (uint32_t)offsets[b->order[p]];
+        ord32[p] = b->order[p];
     }
     for (uint32_t p = 0; p <= n_seq; ++p) off32[p] = (uint32_t)b->offsets[p] + 2 * p;   // two sentinel frames behind every sequence
     auto fail = [&](int rc) { apd_batch_destroy(b); return rc; };
@@ -261,34 +294,65 @@ extern "C" int apd_batch_create(apd_context *ctx, const float *frames, const uin
     const size_t padded_bytes = std::max<size_t>((size_t)padded_frames * b->dpad * sizeof(float), 16);
     b->frames_bytes = padded_bytes < 0xFFFFFE00ull ? (uint32_t)padded_bytes : 0u;
     if (hipMalloc((void **)&b->d_frames, padded_bytes) != hipSuccess) return fail(APD_ERR_OOM);
-    if (hipMalloc((void **)&b->d_seq_off, (n_seq + 1) * sizeof(uint32_t)) != hipSuccess) return fail(APD_ERR_OOM);
-    if (hipMalloc((void **)&b->d_src_off, (n_seq + 1) * sizeof(uint32_t)) != hipSuccess) return fail(APD_ERR_OOM);
-    if (hipMalloc((void **)&b->d_order, (n_seq + 1) * sizeof(uint32_t)) != hipSuccess) return fail(APD_ERR_OOM);
-    if (hipMemcpyAsync(b->d_seq_off, off32.data(), (n_seq + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-        return fail(APD_ERR_HIP);
-    if (hipMemcpyAsync(b->d_src_off, src32.data(), (n_seq + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-        return fail(APD_ERR_HIP);
-    if (n_seq && hipMemcpyAsync(b->d_order, b->order.data(), n_seq * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-        return fail(APD_ERR_HIP);
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(APD_ERR_HIP);    // off32 is a stack-lifetime buffer
+    if (hipMalloc((void **)&b->d_meta, b->h_meta.size() * sizeof(uint32_t)) != hipSuccess) return fail(APD_ERR_OOM);
+    b->d_seq_off = b->d_meta; b->d_src_off = b->d_meta + m1; b->d_order = b->d_meta + 2 * m1; b->d_flags = b->d_meta + 3 * m1;
+    if (hipMemcpyAsync(b->d_meta, b->h_meta.data(), b->h_meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return fail(APD_ERR_HIP);                                         // h_meta lives as long as the batch: no sync needed
+    ctx->batches.insert(b);
+    const int rc_fill = apd_batch_refill(ctx, b, frames, frames_on_device);
+    if (rc_fill != APD_OK) return fail(rc_fill);
+    *out = b;
+    return APD_OK;
+}
+
+extern "C" int apd_batch_refill(apd_context *ctx, apd_batch *b, const float *frames, int frames_on_device)
+{
+    if (!ctx || !b || b->ctx != ctx) return APD_ERR_INVALID_ARG;
+    const uint64_t total = b->total_frames, padded_frames = total + 2ull * b->n_seq;
+    if (total > 0 && !frames) return APD_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    b->nonfinite = -1;
+    HIP_TRY(ctx, hipMemsetAsync(b->d_flags, 0, 4 * sizeof(uint32_t), ctx->stream));
     if (padded_frames > 0) {
         const float *d_src = frames;
         float *d_tmp = nullptr;
+        const uint32_t dim = b->src_dim;
         if (!frames_on_device && total > 0) {
-            if (hipMalloc((void **)&d_tmp, (size_t)total * dim * sizeof(float)) != hipSuccess) return fail(APD_ERR_OOM);
+            if (hipMalloc((void **)&d_tmp, (size_t)total * dim * sizeof(float)) != hipSuccess) return APD_ERR_OOM;
             if (hipMemcpyAsync(d_tmp, frames, (size_t)total * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
                 hipFree(d_tmp);
-                return fail(APD_ERR_HIP);
+                return APD_ERR_HIP;
             }
             d_src = d_tmp;
         }
-        hipError_t e = launch_pad(d_src, b->d_frames, b->d_seq_off, b->d_src_off, n_seq, padded_frames, dim, b->dim, b->dpad, ctx->stream);
+        hipError_t e = launch_pad(d_src, b->d_frames, b->d_seq_off, b->d_src_off, b->n_seq, padded_frames, dim, b->dim, b->dpad, b->d_flags, ctx->stream);
         if (d_tmp) { hipStreamSynchronize(ctx->stream); hipFree(d_tmp); }
-        if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return fail(APD_ERR_HIP); }
+        if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return APD_ERR_HIP; }
     }
-    ctx->batches.insert(b);
-    *out = b;
     return APD_OK;
+}
+
+// The repack kernel's verdict on the frames, read back once per fill (4 bytes, one stream sync).
+static int batch_nonfinite(apd_context *ctx, const apd_batch *b, bool *out)
+{
+    if (b->nonfinite < 0) {
+        uint32_t f = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&f, b->d_flags, sizeof(f), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        b->nonfinite = f ? 1 : 0;
+    }
+    *out = b->nonfinite == 1;
+    return APD_OK;
+}
+
+extern "C" int apd_batch_nonfinite(apd_context *ctx, const apd_batch *b, int *nonfinite)
+{
+    if (!ctx || !b || !nonfinite || b->ctx != ctx) return APD_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    bool nf = false;
+    const int rc = batch_nonfinite(ctx, b, &nf);
+    *nonfinite = nf ? 1 : 0;
+    return rc;
 }
 
 static void release_batch_device_memory(apd_batch *b)
@@ -296,10 +360,8 @@ static void release_batch_device_memory(apd_batch *b)
     for (auto &kv : b->tile_cache) if (kv.second.d_tiles) hipFree(kv.second.d_tiles);
     b->tile_cache.clear();
     if (b->d_frames) hipFree(b->d_frames);
-    if (b->d_seq_off) hipFree(b->d_seq_off);
-    if (b->d_src_off) hipFree(b->d_src_off);
-    if (b->d_order) hipFree(b->d_order);
-    b->d_frames = nullptr; b->d_seq_off = nullptr; b->d_src_off = nullptr; b->d_order = nullptr;
+    if (b->d_meta) hipFree(b->d_meta);
+    b->d_frames = nullptr; b->d_meta = nullptr; b->d_seq_off = nullptr; b->d_src_off = nullptr; b->d_order = nullptr; b->d_flags = nullptr;
 }
 
 extern "C" int apd_batch_destroy(apd_batch *b)
@@ -399,8 +461,9 @@ static int check_lengths(const apd_batch *b)
 // from the lengths of its 32 sequences), one launch per group: a few long or unequal sequences do not force every pair
 // onto a wide kernel.  The plan (device tile list + classes) is cached in the batch.
 static int build_tile_plan(apd_context *ctx, const apd_batch *batch, const BandSpec &band, uint32_t rank, uint32_t world,
-                           bool fast_ok, bool uniform_pen, apd_batch::TilePlan &plan)
+                           bool fast_ok, bool uniform_pen, apd_batch::TilePlan &plan_out)
 {
+    apd_batch::TilePlan plan;                                             // built locally, published only when complete
     std::vector<uint2> tiles;
     rank_tile_list(batch->n_seq, rank, world, tiles);
     // per tile-row (16 sequences) min / max length
@@ -492,9 +555,15 @@ static int build_tile_plan(apd_context *ctx, const apd_batch *batch, const BandS
             std::fprintf(stderr, "[apd] rank %u/%u: geometry %d: %u tiles, w_max %u, n_max %u\n", rank, world, tc.geom_key, tc.count, tc.w_max, tc.n_max);
     HIP_TRY(ctx, hipMalloc((void **)&plan.d_tiles, std::max<size_t>(flat.size(), 1) * sizeof(uint4)));
     if (!flat.empty()) {
-        HIP_TRY(ctx, hipMemcpyAsync(plan.d_tiles, flat.data(), flat.size() * sizeof(uint4), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        hipError_t e = hipMemcpyAsync(plan.d_tiles, flat.data(), flat.size() * sizeof(uint4), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {                                            // never leave a half-made plan in the cache
+            hipFree(plan.d_tiles);
+            ctx->last_error = std::string("tile plan upload: ") + hipGetErrorString(e);
+            return APD_ERR_HIP;
+        }
     }
+    plan_out = std::move(plan);
     return APD_OK;
 }
 
@@ -507,18 +576,27 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const bool pens_ok = (band.ins > 0.0f) && (band.del > 0.0f) && (band.mat > 0.0f) && (band.ins < INFINITY) &&
                          (band.del < INFINITY) && (band.mat < INFINITY);   // the systolic kernel needs pen * INF = INF
-    const bool fast_ok = pens_ok && batch->frames_bytes != 0;
+    bool nonfinite = false;                                               // a NaN / infinite feature anywhere: literal kernel only
+    rc = batch_nonfinite(ctx, batch, &nonfinite);
+    if (rc) return rc;
+    const bool fast_ok = pens_ok && batch->frames_bytes != 0 && !nonfinite;
     const bool uniform_pen = (band.ins == band.del) && (band.del == band.mat);
     char keybuf[160];
     uint32_t pct_bits;
     std::memcpy(&pct_bits, &band.pct, sizeof(pct_bits));
     std::snprintf(keybuf, sizeof(keybuf), "%u/%u/%08x/%u/%d/%d/%d/%d", rank, world, pct_bits, band.explicit_band, band.use_explicit,
                   ctx->variant, (int)fast_ok, (int)uniform_pen);   // everything the choice of kernels depends on
-    apd_batch::TilePlan &plan = batch->tile_cache[keybuf];
-    if (!plan.d_tiles) {
-        rc = build_tile_plan(ctx, batch, band, rank, world, fast_ok, uniform_pen, plan);
+    auto cached = batch->tile_cache.find(keybuf);
+    if (cached == batch->tile_cache.end()) {
+        apd_batch::TilePlan fresh;
+        rc = build_tile_plan(ctx, batch, band, rank, world, fast_ok, uniform_pen, fresh);
         if (rc) return rc;
+        cached = batch->tile_cache.emplace(keybuf, std::move(fresh)).first;
     }
+    const apd_batch::TilePlan &plan = cached->second;
+    // Poison: every score slot of the rank's slab starts as NaN, so a pair that no kernel writes (a launch cut short, a
+    // skipped class) reaches the matrix as NaN and raises APD_ERR_INCOMPLETE in the unpack -- never a stale or zero distance.
+    HIP_TRY(ctx, hipMemsetAsync(d_slab, 0xFF, apd_slab_floats(batch->n_seq, world) * sizeof(float), ctx->stream));
     AlignLaunch L{};
     L.d_frames = batch->d_frames; L.frames_bytes = batch->frames_bytes; L.d_seq_off = batch->d_seq_off;
     L.n_seq = batch->n_seq; L.dim = batch->dim; L.dpad = batch->dpad; L.band = band; L.d_slab = d_slab;
@@ -537,6 +615,7 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
     size_t ci = 0;
     for (const apd_batch::TileClass &tc : plan.classes) {
         L.d_tiles = plan.d_tiles + tc.first; L.n_tiles = tc.count; L.w_max = tc.w_max; L.n_max = tc.n_max;
+        if (ctx->drop_tiles) L.n_tiles -= std::min(L.n_tiles, ctx->drop_tiles);   // fault injection (apd_set_fault_injection)
         int status = APD_OK;
         hipStream_t s = fan_out ? ctx->side[ci++ % apd_context::kSideStreams] : ctx->stream;
         hipError_t e = launch_align(L, tc.geom_key, s, ctx->last_error, &status);
@@ -574,8 +653,10 @@ extern "C" int apd_unpack_tiles_async(apd_context *ctx, const apd_batch *batch, 
     if (!ctx || !batch || batch->ctx != ctx || !d_gathered || !d_out || world == 0) return APD_ERR_INVALID_ARG;
     const uint32_t n_seq = batch->n_seq;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemsetAsync(d_out, 0, (size_t)n_seq * n_seq * sizeof(float), ctx->stream));   // alignments.rs:21-23
-    HIP_TRY(ctx, launch_unpack(d_gathered, d_out, batch->d_order, n_seq, world, apd_slab_floats(n_seq, world), ctx->stream));
+    // the unpack writes every entry, the zero diagonal (alignments.rs:21-23) included; anything it fails to write stays NaN
+    HIP_TRY(ctx, hipMemsetAsync(d_out, 0xFF, (size_t)n_seq * n_seq * sizeof(float), ctx->stream));
+    HIP_TRY(ctx, launch_unpack(d_gathered, d_out, batch->d_order, n_seq, world, apd_slab_floats(n_seq, world), batch->d_flags,
+                               ctx->d_status, ctx->stream));
     return APD_OK;
 }
 
@@ -608,8 +689,8 @@ extern "C" int apd_align_all(apd_context *ctx, const apd_batch *batch, const apd
     int rc = align_all_device_impl(ctx, batch, band_from_cfg(cfg), d_out);
     if (rc == APD_OK) {
         hipError_t e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); rc = APD_ERR_HIP; }
+        else rc = sync_and_report(ctx);                                   // APD_ERR_INCOMPLETE: `out` holds NaN where no score was written
     }
     hipFree(d_out);
     return rc;
@@ -639,8 +720,8 @@ extern "C" int apd_align_pair(apd_context *ctx, const float *x, uint64_t n, cons
     float host[4] = {0, 0, 0, 0};
     if (rc == APD_OK) {
         hipError_t e = hipMemcpyAsync(host, d_out, sizeof(host), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); rc = APD_ERR_HIP; }
+        else rc = sync_and_report(ctx);
     }
     hipFree(d_out);
     apd_batch_destroy(b);

@@ -62,10 +62,13 @@ int pick_full_key(uint32_t cols, uint32_t rows, uint32_t dim, int variant);   //
 double full_key_cost(uint32_t cols, uint32_t rows, uint32_t dim, int key);    // modelled cost of one pair on that geometry (+inf: does not apply)
 // >= 30000: the same column strips with a binding band (two DPs): 30000 + (pairs per wavefront) * 100 + CW
 int pick_banded_strip_key(uint32_t cols, uint32_t rows, uint32_t dim, int variant);
+// d_flags[0] is raised when a frame holds a NaN or an infinity (the fast kernels' selects and sentinels assume finite features)
 hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_off, const uint32_t *d_src_off, uint32_t n_seq,
-                      uint64_t n_frames_padded, uint32_t src_dim, uint32_t dim, uint32_t dpad, hipStream_t stream);
+                      uint64_t n_frames_padded, uint32_t src_dim, uint32_t dim, uint32_t dpad, uint32_t *d_flags, hipStream_t stream);
+// writes EVERY entry of d_out (diagonal included); *d_status |= 1 when a pair score of a batch with finite frames is NaN,
+// i.e. still carries the poison its slab was filled with before the alignment launches
 hipError_t launch_unpack(const float *d_gathered, float *d_out, const uint32_t *d_order, uint32_t n_seq, uint32_t world,
-                         uint64_t slab_floats, hipStream_t stream);
+                         uint64_t slab_floats, const uint32_t *d_flags, uint32_t *d_status, hipStream_t stream);
 hipError_t launch_selftest(int *d_result, hipStream_t stream);
 
 // numerics.rs:125-133 on a device array (clustering.hip): radix select of the k-th smallest non-NaN value.
@@ -113,6 +116,9 @@ struct apd_context {
     void *ws_tiles = nullptr; size_t ws_tiles_bytes = 0;
     void *ws_slab = nullptr; size_t ws_slab_bytes = 0;
     void *ws_misc = nullptr; size_t ws_misc_bytes = 0;
+    void *ws_gather = nullptr; size_t ws_gather_bytes = 0;   // gathered slabs of apd_align_all_sharded_async
+    uint32_t *d_status = nullptr;     // sticky device word: bit 0 = an unpack met an unwritten (poisoned) pair score
+    uint32_t drop_tiles = 0;          // fault injection (apd_set_fault_injection)
 };
 
 struct apd_batch {
@@ -122,9 +128,13 @@ struct apd_batch {
     uint64_t total_frames = 0;
     float *d_frames = nullptr;        // padded layout with sentinels (see dtw_generic.hip)
     uint32_t frames_bytes = 0;
+    uint32_t *d_meta = nullptr;       // ONE allocation: [seq_off n+1 | src_off n+1 | order n+1 | flags 4], filled by one copy of h_meta
+    std::vector<uint32_t> h_meta;     // host image of d_meta, alive as long as the batch (the H2D copy is asynchronous)
     uint32_t *d_seq_off = nullptr;
     uint32_t *d_src_off = nullptr;    // first frame of resident sequence p in the caller's frame array
     uint32_t *d_order = nullptr;      // resident position p -> caller's sequence index
+    uint32_t *d_flags = nullptr;      // [0] 1: some frame holds a NaN / infinity (raised by the repack kernel)
+    mutable int nonfinite = -1;       // host copy of d_flags[0]; -1: not read back yet
     std::vector<uint32_t> order;      // host copy of d_order
     std::vector<uint64_t> offsets;    // frame offsets of the RESIDENT order (host)
     uint32_t min_len = 0, max_len = 0;

@@ -111,9 +111,10 @@ __global__ __launch_bounds__(64) void dtw_fused_generic(const AlignLaunch L, int
 // ------------------------------------------------------------------------------------------------
 __global__ void pad_frames_kernel(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ seq_off,
                                   const uint32_t *__restrict__ src_off, uint32_t n_seq, uint64_t n_frames_padded, uint32_t src_dim,
-                                  uint32_t dim, uint32_t dpad)
+                                  uint32_t dim, uint32_t dpad, uint32_t *__restrict__ flags)
 {
     const uint64_t total = n_frames_padded * dpad;
+    bool nonfinite = false;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t f = (uint32_t)(e / dpad);
         const uint32_t k = (uint32_t)(e - (uint64_t)f * dpad);
@@ -125,16 +126,20 @@ __global__ void pad_frames_kernel(const float *__restrict__ src, float *__restri
         else if (sent_h) v = (k == dim) ? APD_INF : 0.0f;
         else {
             const float *fr = src + (uint64_t)(src_off[lo] + (f - seq_off[lo])) * src_dim;
-            if (k < src_dim) v = fr[k];                       // components src_dim .. dim - 1 stay zero
+            if (k < src_dim) { v = fr[k]; nonfinite |= !(__builtin_fabsf(v) < APD_INF); }   // NaN or +-INF; components src_dim .. dim - 1 stay zero
             else if (k == dim) { double acc = 0.0; for (uint32_t t = 0; t < src_dim; ++t) acc += (double)fr[t] * (double)fr[t]; v = (float)acc; }
         }
         dst[e] = v;
     }
+    // the fast kernels assume finite features (fminf-based select, +INF sentinels, norm expansion): a batch with a NaN or an
+    // infinity anywhere is routed to the literal kernel, where NaN compares false and takes MATCH as in alignments.rs:153-159
+    if (__ballot(nonfinite) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flags, 1u);
 }
 
 // gathered: `world` slabs of slab_floats each; slab r holds tiles r, r+world, ... in order.
 __global__ void unpack_tiles_kernel(const float *__restrict__ gathered, float *__restrict__ out,
-                                    const uint32_t *__restrict__ order, uint32_t n_seq, uint32_t world, uint64_t slab_floats, uint32_t n_tiles_side)
+                                    const uint32_t *__restrict__ order, uint32_t n_seq, uint32_t world, uint64_t slab_floats, uint32_t n_tiles_side,
+                                    const uint32_t *__restrict__ flags, uint32_t *__restrict__ status)
 {
     const uint32_t g = blockIdx.x;                            // (ta, tb), ta <= tb, row-major over the upper triangle
     uint32_t ta = 0, rem = g, row = n_tiles_side;
@@ -144,11 +149,20 @@ __global__ void unpack_tiles_kernel(const float *__restrict__ gathered, float *_
     const float *slab = gathered + (uint64_t)rank * slab_floats + (uint64_t)local * 2 * kSlotsPerTile;
     const int sa = threadIdx.x / kTile, sb = threadIdx.x % kTile;
     const uint32_t pa = ta * kTile + sa, pb = tb * kTile + sb;   // positions in the resident (length) order
+    bool poisoned = false;
     if (pa < pb && pb < n_seq) {
         const uint32_t a = order[pa], b = order[pb];
-        out[(uint64_t)a * n_seq + b] = slab[sa * kTile + sb];
-        out[(uint64_t)b * n_seq + a] = slab[kSlotsPerTile + sa * kTile + sb];
+        const float s1 = slab[sa * kTile + sb], s2 = slab[kSlotsPerTile + sa * kTile + sb];
+        out[(uint64_t)a * n_seq + b] = s1;
+        out[(uint64_t)b * n_seq + a] = s2;
+        poisoned = (s1 != s1) | (s2 != s2);
+    } else if (pa == pb && pb < n_seq) {
+        const uint32_t a = order[pa];
+        out[(uint64_t)a * n_seq + a] = 0.0f;                  // the diagonal is never aligned (alignments.rs:21-23, 51)
     }
+    // every slab is filled with NaN before the alignment launches: with finite frames no score is NaN, so a NaN here is a
+    // pair no kernel wrote (a launch cut short or skipped).  It stays NaN in the matrix and is reported, never a silent 0.
+    if (__ballot(poisoned) != 0ull && (threadIdx.x & 63) == 0 && flags[0] == 0u) atomicOr(status, 1u);
 }
 
 __global__ void selftest_kernel(int *result)
@@ -175,24 +189,24 @@ hipError_t launch_selftest(int *d_result, hipStream_t stream)
 }
 
 hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_off, const uint32_t *d_src_off, uint32_t n_seq,
-                      uint64_t n_frames_padded, uint32_t src_dim, uint32_t dim, uint32_t dpad, hipStream_t stream)
+                      uint64_t n_frames_padded, uint32_t src_dim, uint32_t dim, uint32_t dpad, uint32_t *d_flags, hipStream_t stream)
 {
     if (n_frames_padded == 0) return hipSuccess;
     const uint64_t total = n_frames_padded * dpad;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 16384);
     hipLaunchKernelGGL(pad_frames_kernel, dim3(blocks), dim3(256), 0, stream, d_src, d_dst, d_seq_off, d_src_off, n_seq, n_frames_padded,
-                       src_dim, dim, dpad);
+                       src_dim, dim, dpad, d_flags);
     return hipGetLastError();
 }
 
 hipError_t launch_unpack(const float *d_gathered, float *d_out, const uint32_t *d_order, uint32_t n_seq, uint32_t world,
-                         uint64_t slab_floats, hipStream_t stream)
+                         uint64_t slab_floats, const uint32_t *d_flags, uint32_t *d_status, hipStream_t stream)
 {
     const uint32_t side = (n_seq + kTile - 1) / kTile;
     const uint64_t n_tiles = (uint64_t)side * (side + 1) / 2;
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(unpack_tiles_kernel, dim3((uint32_t)n_tiles), dim3(kSlotsPerTile), 0, stream, d_gathered, d_out,
-                       d_order, n_seq, world, slab_floats, side);
+                       d_order, n_seq, world, slab_floats, side, d_flags, d_status);
     return hipGetLastError();
 }
 

@@ -59,3 +59,62 @@ def unpack_host(offsets, world, gathered):
     _lib.check(_lib.lib().apd_unpack_tiles_host(off.ctypes.data_as(C.POINTER(C.c_uint64)), n_seq, world, g.ctypes.data_as(C.POINTER(C.c_float)),
                                                 out.ctypes.data_as(C.POINTER(C.c_float))))
     return out
+
+
+class Comm:
+    """apd_comm: this rank's end of the library-owned RCCL communicator (one process per GPU).  Rank 0 makes the id with
+    ``Comm.unique_id()`` and hands its 128 bytes to the other ranks over any host channel."""
+
+    def __init__(self, ctx, id_bytes, rank, world):
+        if len(id_bytes) != _lib.APD_COMM_ID_BYTES:
+            raise ValueError("communicator ids are %d bytes" % _lib.APD_COMM_ID_BYTES)
+        self.ctx = ctx
+        self.handle = C.c_void_p()
+        buf = C.create_string_buffer(bytes(id_bytes), _lib.APD_COMM_ID_BYTES)
+        _lib.check(_lib.lib().apd_comm_create(ctx.handle, buf, int(rank), int(world), C.byref(self.handle)), ctx.handle)
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(_lib.APD_COMM_ID_BYTES)
+        _lib.check(_lib.lib().apd_comm_unique_id(buf))
+        return buf.raw
+
+    def count(self):
+        """ncclCommCount: the ranks RCCL actually sees."""
+        n = C.c_uint32(0)
+        _lib.check(_lib.lib().apd_comm_count(self.handle, C.byref(n)), self.ctx.handle)
+        return int(n.value)
+
+    def rank(self):
+        r = C.c_uint32(0)
+        _lib.check(_lib.lib().apd_comm_rank(self.handle, C.byref(r)), self.ctx.handle)
+        return int(r.value)
+
+    def align_all_sharded_async(self, batch_handle, cfg, d_out_ptr):
+        """This rank's pair tiles + ONE ncclAllGather + unpack, on the context's stream; d_out_ptr: device address of n*n floats."""
+        _lib.check(_lib.lib().apd_align_all_sharded_async(self.ctx.handle, self.handle, batch_handle, C.byref(cfg), C.c_void_p(int(d_out_ptr))),
+                   self.ctx.handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.lib().apd_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def align_all_multi(devices, frames, offsets, dim, cfg):
+    """apd_align_all_multi: ONE process, len(devices) GPUs (ncclCommInitAll).  Returns ((n, n) matrix, ranks RCCL saw)."""
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    fr = np.ascontiguousarray(frames, dtype=np.float32)
+    n = len(off) - 1
+    out = np.empty((n, n), dtype=np.float32)
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    seen = C.c_uint32(0)
+    _lib.check(_lib.lib().apd_align_all_multi(devs, len(devices), fr.ctypes.data_as(C.POINTER(C.c_float)), off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                              n, int(dim), C.byref(cfg), out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(seen)))
+    return out, int(seen.value)

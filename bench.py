@@ -7,10 +7,15 @@ src/alignments.rs:31-67) on synthetic MFCC-like sequences, one process per GPU.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = one full pass of the path over the resident batch: repack the [sum len][D] frames into
-the kernels' padded layout, fused-pair DTW over this rank's pair tiles, ONE all-gather of the
-packed tile slabs (RCCL via torch.distributed's "nccl" backend), unpack into the N x N matrix.
-The pair set is fixed as ranks are added (strong scaling).  torch is plumbing only: device
-buffers, the stream and the collective; the compute is libapd_hip.so through its C ABI.
+the kernels' padded layout (apd_batch_refill), fused-pair DTW over this rank's pair tiles, ONE
+ncclAllGather of the packed tile slabs, unpack into the N x N matrix -- the last three are ONE call,
+apd_align_all_sharded_async, on a communicator the LIBRARY owns (apd_comm_create: RCCL over xGMI,
+include/apd.h).  The pair set is fixed as ranks are added (strong scaling).  torch is plumbing
+only: device buffers, the stream, and a gloo process group for the control plane (handing the
+128-byte communicator id to the ranks, barriers, the max over ranks of the elapsed time); the
+compute AND the data-path collective are libapd_hip.so through its C ABI.  If the library's
+communicator cannot be made on some rank, every rank falls back to torch.distributed's "nccl"
+all_gather_into_tensor and the JSON line says so ("collective").
 
 Prints ONE JSON line on rank 0 (metric: DTW cell-updates/s, whole job), with
   roofline     -- algorithmic bytes (4*D*(n+m)+4 per ordered pair) / measured kernel time vs 8 TB/s
@@ -79,8 +84,9 @@ def parse():
     ap.add_argument("--distance", default="hybrid", choices=["hybrid", "exact"], help="local-distance form (apd_set_distance_mode)")
     ap.add_argument("--tau", type=float, default=0.0, help="hybrid recomputation threshold (0 = library default 1/64)")
     ap.add_argument("--cluster", action="store_true", help="also time percentile + UPGMA (rank 0, outside the timed region)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="collective backend; gloo (staged through host memory) only to rehearse N>1 on a box with fewer GPUs")
+    ap.add_argument("--backend", default="apd", choices=["apd", "nccl", "gloo"],
+                    help="data-path collective: apd = the library's own RCCL communicator (default); nccl = torch.distributed's; "
+                         "gloo (staged through host memory) only to rehearse N>1 on a box with fewer GPUs")
     return ap.parse_args()
 
 
@@ -146,11 +152,11 @@ def main():
     dev_index = int(os.environ.get("APD_FORCE_DEVICE", local_rank))      # rehearsal: several ranks on one GPU
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    nccl_group = None
     if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)       # control plane only
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            nccl_group = dist.new_group(backend="nccl", device_id=dev)
 
     wl = WORKLOADS[args.workload]
     n, dim = wl["n_seq"], wl["dim"]
@@ -196,10 +202,42 @@ def main():
     f32p = C.POINTER(C.c_float)
     off_c = np.ascontiguousarray(offsets, dtype=np.uint64)
     slab_floats = int(L.apd_slab_floats(n, world))
-    d_slab = torch.zeros(slab_floats, dtype=torch.float32, device=dev)
-    d_gathered = torch.zeros(slab_floats * world, dtype=torch.float32, device=dev) if world > 1 else d_slab
     d_out = torch.empty(n * n, dtype=torch.float32, device=dev)
     kernel_ms = []
+    # the library-owned communicator (one process per GPU: rank 0 makes the id, the control plane hands it out)
+    comm, ranks_seen, collective = None, 1, "none (1 rank)"
+    if world > 1 and args.backend == "apd":
+        from audio_pattern_discovery_amd import sharding
+        box = [sharding.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ok = 1
+        try:
+            comm = sharding.Comm(ctx, box[0], rank, world)
+            ranks_seen = comm.count()
+        except Exception as exc:                                         # noqa: BLE001 -- any failure: agree on the fallback
+            sys.stderr.write("[bench] rank %d: apd_comm_create failed (%s); falling back to torch.distributed nccl\n" % (rank, exc))
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            collective = "apd_comm: library-owned RCCL communicator, ncclAllGather inside apd_align_all_sharded_async"
+        else:
+            if comm is not None:
+                comm.close()
+                comm = None
+            args.backend = "nccl"
+            nccl_group = dist.new_group(backend="nccl", device_id=dev)
+    if world > 1 and args.backend == "nccl":
+        collective = "torch.distributed all_gather_into_tensor (nccl = RCCL)"
+        ranks_seen = dist.get_world_size(nccl_group)
+    elif world > 1 and args.backend == "gloo":
+        collective = "gloo through host memory (rehearsal only)"
+    if comm is None:
+        d_slab = torch.zeros(slab_floats, dtype=torch.float32, device=dev)
+        d_gathered = torch.zeros(slab_floats * world, dtype=torch.float32, device=dev) if world > 1 else d_slab
+    # AlignmentWorkers::new once; every step refills the resident copy from the features it just made (same lengths), so the
+    # device buffers and the tile plans are made once, not per step
+    batch = C.c_void_p()
 
     def step():
         if audio is not None:                                        # NDSequence::new on the whole corpus, in HBM
@@ -209,20 +247,26 @@ def main():
         if enc_w is not None:                                        # NDSequence::encoded on the whole corpus, in HBM
             _lib.check(L.apd_encode(ctx.handle, C.c_void_p(d_src.data_ptr()), total_frames, src_dim, enc_w.ctypes.data_as(f32p),
                                     enc_b.ctypes.data_as(f32p), dim, 1, C.c_void_p(d_frames.data_ptr())), ctx.handle)
-        batch = C.c_void_p()
-        _lib.check(L.apd_batch_create(ctx.handle, C.c_void_p(d_frames.data_ptr()), off_c.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                      n, dim, 1, C.byref(batch)), ctx.handle)
+        if not batch:
+            _lib.check(L.apd_batch_create(ctx.handle, C.c_void_p(d_frames.data_ptr()), off_c.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                          n, dim, 1, C.byref(batch)), ctx.handle)
+        else:
+            _lib.check(L.apd_batch_refill(ctx.handle, batch, C.c_void_p(d_frames.data_ptr()), 1), ctx.handle)
+        if comm is not None or world == 1:
+            # tiles of this rank + the one ncclAllGather (RCCL over xGMI) + unpack, all inside the library
+            _lib.check(L.apd_align_all_sharded_async(ctx.handle, comm.handle if comm is not None else None, batch, C.byref(cfg),
+                                                     C.c_void_p(d_out.data_ptr())), ctx.handle)
+            return
         _lib.check(L.apd_align_tiles_async(ctx.handle, batch, C.byref(cfg), rank, world, C.c_void_p(d_slab.data_ptr())),
                    ctx.handle)
-        if world > 1 and args.backend == "nccl":
-            dist.all_gather_into_tensor(d_gathered, d_slab)          # the one collective (RCCL over xGMI)
-        elif world > 1:
+        if args.backend == "nccl":
+            dist.all_gather_into_tensor(d_gathered, d_slab, group=nccl_group)
+        else:
             host = torch.empty(slab_floats * world, dtype=torch.float32)
             dist.all_gather_into_tensor(host, d_slab.cpu())          # rehearsal path only
             d_gathered.copy_(host)
         _lib.check(L.apd_unpack_tiles_async(ctx.handle, batch, world, C.c_void_p(d_gathered.data_ptr()),
                                             C.c_void_p(d_out.data_ptr())), ctx.handle)
-        return batch
 
     def fence():
         torch.cuda.synchronize()
@@ -230,21 +274,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        L.apd_batch_destroy(step())
+    for _ in range(max(args.warmup, 0)):
+        step()
+    if not batch:                                                    # --warmup 0: AlignmentWorkers::new is not part of a step
+        _lib.check(L.apd_batch_create(ctx.handle, C.c_void_p(d_frames.data_ptr()), off_c.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                      n, dim, 1, C.byref(batch)), ctx.handle)
     fence()
     t0 = time.perf_counter()
-    batches = []
     for _ in range(args.steps):
-        batches.append(step())
+        step()
         ms = ctx.last_kernel_ms()                                    # syncs on the kernel's end event only
         kernel_ms.append(ms)
     fence()
     elapsed = time.perf_counter() - t0
-    for b in batches:
-        L.apd_batch_destroy(b)
+    ctx.synchronize()                                                # raises APD_ERR_INCOMPLETE if any unpack met an unwritten score
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -286,22 +331,29 @@ def main():
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "n_seq": n, "nominal_len": wl["length"],
                        "dim": dim, "warping_band_percentage": wl["pct"], "ordered_pairs": pairs_all,
                        "cells_per_step": cells_all, "sharding": "pair tiles 16x16, cyclic over %d ranks, 1 all-gather" % world,
+                       "collective": collective, "ranks_seen": ranks_seen,
                        "kernel_variant": args.variant, "distance_form": args.distance},
             "wall_clock_matrix_s": elapsed / args.steps,
             "pairs_per_s": pairs_all * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": None if traffic is None else
+                         "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this command, committed; "
+                         "a recorded constant, not re-measured in this run",
+                         "note": "rows n / columns m of every pair are not swept (score() reads cell (n-1, m-1), alignments.rs:120): "
+                                 "the kernel touches ~0.2 % fewer cells than `value` counts; `value` counts the reference's cells",
                          "kernel": "dtw_fused (rank 0 share: %d ordered pairs)" % pairs_r,
                          "kernel_ms": k_ms, "alg_bytes_per_launch": bytes_r,
                          "kernel_cells_per_s": cells_r / (k_ms * 1e-3)},
             # the kernel is VALU-bound, so the HBM fraction above is reported next to the vector-issue figure:
             # lane-instructions per cell from the SQ_INSTS_VALU counter of this workload, times the live cell rate, over the
-            # 3.9e13 lane-instr/s of 1024 SIMDs x 16 lanes x 2.4 GHz (MI355X issues simple f32 ops faster than that: > 1 is possible)
+            # 7.86e13 lane-instr/s of 1024 SIMDs x 32 lanes x 2.4 GHz (gfx950 SIMDs are 32 lanes wide: 157.3 TFLOP/s f32 / 2)
             "valu": None if not valu_insts else {
                 "lane_instr_per_cell": valu_insts * 64.0 / cells_r,
                 "lane_instr_per_s": valu_insts * 64.0 / (k_ms * 1e-3),
-                "frac_of_16_lanes_per_simd_clk": valu_insts * 64.0 / (k_ms * 1e-3) / (1024 * 16 * 2.4e9),
-                "source": "profiles/hbm_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU)"},
+                "peak_lane_instr_per_s": 1024 * 32 * 2.4e9,
+                "frac": valu_insts * 64.0 / (k_ms * 1e-3) / (1024 * 32 * 2.4e9),
+                "source": "profiles/hbm_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU of this command, committed; not re-measured in this run)"},
             "max_rel_err_vs_oracle": verify, "parity_ok": (verify is None) or bool(verify <= (1e-3 if audio is not None else 1e-4)),
         }
         if frames is not None and enc_w is None and world == 1:
@@ -338,6 +390,10 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
+    if batch:
+        L.apd_batch_destroy(batch)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -35,11 +35,16 @@ typedef enum apd_status {
     APD_ERR_EMPTY_SEQUENCE = -5, /* a zero-length sequence: the reference underflows usize at alignments.rs:120 */
     APD_ERR_BAND_TOO_WIDE = -6,  /* 2*w+1 exceeds what one wavefront's LDS state can hold */
     APD_ERR_INDEX = -7,          /* percentile index past the data: the reference panics at numerics.rs:132 */
-    APD_ERR_UNSUPPORTED = -8
+    APD_ERR_UNSUPPORTED = -8,
+    APD_ERR_INCOMPLETE = -9,     /* a pair score was never written (a launch was cut short or skipped): the output holds NaN
+                                    there.  The reference swallows a failed worker and leaves silent zeros
+                                    (alignments.rs:64-66); this library poisons and reports instead */
+    APD_ERR_COMM = -10           /* an RCCL call failed: apd_last_error() has the text */
 } apd_status;
 
 typedef struct apd_context apd_context;   /* one GPU + one HIP stream + workspaces */
 typedef struct apd_batch apd_batch;       /* Arc<Vec<NDSequence>> resident in HBM (alignments.rs:12) */
+typedef struct apd_comm apd_comm;         /* this rank's end of an RCCL communicator over the GPUs that share the pair tiles */
 
 /* The four Discovery fields the path reads (src/discovery.rs:17-20, project/config/Discovery.toml:17-20). */
 typedef struct apd_align_config {
@@ -74,6 +79,8 @@ int apd_create(int device, apd_context **ctx);
 int apd_destroy(apd_context *ctx);
 /* Run on the caller's hipStream_t (e.g. torch's current stream) instead of the context's own. */
 int apd_set_stream(apd_context *ctx, void *hip_stream);
+/* Waits for the context's stream.  Also reports (once) what asynchronous calls found since the last report:
+ * APD_ERR_INCOMPLETE if an unpack met a pair score that no kernel wrote. */
 int apd_synchronize(apd_context *ctx);
 const char *apd_status_string(int status);
 const char *apd_last_error(apd_context *ctx);
@@ -94,6 +101,10 @@ int apd_set_variant(apd_context *ctx, int variant);
 int apd_set_distance_mode(apd_context *ctx, int mode, float tau);
 /* Device self-test of the cross-lane primitives the kernels rely on (DPP wave shifts). */
 int apd_selftest(apd_context *ctx);
+/* TEST HOOK (fault injection): the next alignment launches leave the last `drop_tiles` tiles of every kernel class
+ * unprocessed, as a launch that is cut short would.  0 = off.  Exists so that the poison / APD_ERR_INCOMPLETE path can
+ * be tested (tests/test_gpu_dtw.py); never set it in production. */
+int apd_set_fault_injection(apd_context *ctx, uint32_t drop_tiles);
 
 /* ---- Discovery::alignment_params (src/discovery.rs:38-45) ----------------------------- */
 int apd_discovery_alignment_params(const apd_align_config *cfg, uint64_t n_size, apd_alignment_params *out);
@@ -107,6 +118,13 @@ int apd_batch_create(apd_context *ctx, const float *frames, const uint64_t *offs
                      uint32_t dim, int frames_on_device, apd_batch **batch);
 int apd_batch_destroy(apd_batch *batch);
 uint32_t apd_batch_len(const apd_batch *batch);
+/* New frame VALUES for the same sequence lengths (the same `offsets` and `dim` the batch was created with): re-runs only
+ * the repack kernel, asynchronously on the context's stream; the batch keeps its device buffers and its cached tile
+ * plans.  For pipelines that call align_all repeatedly on features recomputed in HBM (bench.py's step). */
+int apd_batch_refill(apd_context *ctx, apd_batch *batch, const float *frames, int frames_on_device);
+/* 1 if the resident frames hold a NaN or an infinity (then every pair goes through the literal, NaN-faithful kernel:
+ * NaN compares false and takes the MATCH branch, alignments.rs:153-159), 0 if all are finite.  Synchronises. */
+int apd_batch_nonfinite(apd_context *ctx, const apd_batch *batch, int *nonfinite);
 
 /* ---- AlignmentWorkers::align_all (src/alignments.rs:31-67) ---------------------------- */
 /* out: n_seq*n_seq f32 row-major, out[i*n+j] = Alignment::score of (x = seq i, y = seq j),
@@ -132,6 +150,36 @@ int apd_align_tiles_async(apd_context *ctx, const apd_batch *batch, const apd_al
                           uint32_t rank, uint32_t world, float *d_slab);
 int apd_unpack_tiles_async(apd_context *ctx, const apd_batch *batch, uint32_t world, const float *d_gathered,
                            float *d_out);
+/* ---- the same over several GPUs, collective included (RCCL over xGMI; no torch, no MPI) --------------------------
+ * The reference runs `alignment_workers` threads over row blocks (alignments.rs:33-41); here a worker is a GPU.  Two ways
+ * to bring the GPUs together:
+ *
+ * (1) one PROCESS PER GPU (how bench.py is launched): rank 0 calls apd_comm_unique_id and hands the 128 bytes to every
+ *     rank over whatever channel the host has (a file, a socket, MPI, torch.distributed's store); every rank then calls
+ *     apd_comm_create on its own context.  apd_align_all_sharded_async = this rank's tiles (apd_align_tiles_async) +
+ *     ONE ncclAllGather of the equal-sized slabs on the context's stream + apd_unpack_tiles_async: afterwards EVERY
+ *     rank holds the full n x n matrix in d_out (rank 0 is the consumer: UPGMA runs there).
+ * (2) ONE process driving n_devices GPUs: apd_align_all_multi (ncclCommInitAll, one context + one resident copy of the
+ *     batch per device, per-device streams, the same all-gather inside one ncclGroup, unpack on devices[0], copy to the
+ *     host).  n_devices == 1 degenerates to apd_align_all and returns the identical bits. */
+#define APD_COMM_ID_BYTES 128
+int apd_comm_unique_id(void *id_bytes /* APD_COMM_ID_BYTES */);
+int apd_comm_create(apd_context *ctx, const void *id_bytes, uint32_t rank, uint32_t world, apd_comm **comm);
+int apd_comm_destroy(apd_comm *comm);
+int apd_comm_count(const apd_comm *comm, uint32_t *world);   /* ncclCommCount: the ranks RCCL actually sees */
+int apd_comm_rank(const apd_comm *comm, uint32_t *rank);     /* ncclCommUserRank */
+/* d_out: n_seq*n_seq floats in this rank's HBM; the batch must hold the same sequences on every rank.  Asynchronous on
+ * the context's stream.  With comm == NULL the call is apd_align_all_device_async (world 1). */
+int apd_align_all_sharded_async(apd_context *ctx, apd_comm *comm, const apd_batch *batch, const apd_align_config *cfg,
+                                float *d_out);
+/* The same with the slab gathered by the caller's own transport between the two halves is apd_align_tiles_async +
+ * apd_unpack_tiles_async below.  apd_all_gather_async is the library's collective on its own: d_send (count floats) of
+ * every rank, concatenated in rank order into d_recv (count * world floats), on the context's stream. */
+int apd_all_gather_async(apd_context *ctx, apd_comm *comm, const float *d_send, float *d_recv, uint64_t count);
+/* frames / offsets / out: host memory, as apd_batch_create + apd_align_all take them.  devices: HIP device ordinals. */
+int apd_align_all_multi(const int *devices, uint32_t n_devices, const float *frames, const uint64_t *offsets, uint32_t n_seq,
+                        uint32_t dim, const apd_align_config *cfg, float *out, uint32_t *ranks_seen);
+
 /* Host-side views of the same sharding (no GPU needed): the length order (order[p] = sequence at position p), the
  * (tile_a, tile_b) list of a rank over those positions, 2 uint32 per tile, and the scatter of gathered slabs held in
  * HOST memory (for a host that gathers over its own transport). */

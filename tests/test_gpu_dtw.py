@@ -499,3 +499,156 @@ def test_very_long_sequences_and_the_length_limit(ctx, oracle):
     w2 = AlignmentWorkers.new([NDSequence(a) for a in arrs[1:]], c2)
     c2.close()
     del w2
+
+
+# ---- non-finite features, poison, fault injection ---------------------------------------------------------------
+
+def _assert_same_bits_or_nan(got, want):
+    got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
+    nan = np.isnan(want)
+    assert np.array_equal(nan, np.isnan(got)), "NaN pattern differs"
+    assert np.array_equal(got[~nan].view(np.uint32), want[~nan].view(np.uint32)), "bits differ"
+
+
+@pytest.mark.parametrize("pct,pens", [(0.0625, (1.0, 1.0, 1.0)), (1.0, (1.0, 1.0, 1.0)), (0.25, (0.7, 1.3, 0.9))])
+def test_nonfinite_features_follow_the_reference_select(ctx, oracle, apd, pct, pens):
+    """NaN compares false, so a node whose predecessors or distance are NaN takes the MATCH branch and the NaN propagates
+    (alignments.rs:153-159); an infinite feature gives d = +INF or (INF - INF) NaN.  The fast kernels' fminf select would drop
+    NaNs: the repack kernel flags such a batch and every pair goes through the literal kernel, whose results equal the
+    oracle's bit for bit (NaN payloads aside)."""
+    frames, offsets = synth.make_sequences(20, 40, 13, seed=31, jitter=9)
+    frames = frames.copy()
+    o = offsets.astype(np.int64)
+    frames[o[3] + 5, 2] = np.nan                   # one NaN component in the middle of sequence 3
+    frames[o[7] + 0, :] = np.nan                   # a whole NaN first frame
+    frames[o[9] + 17, 4] = np.inf                  # +INF component
+    frames[o[12] + 30, 0] = -np.inf                # -INF component
+    frames[o[12] + 31, 0] = np.inf
+    frames[o[15 + 1] - 1, 1] = np.nan              # NaN in the LAST frame of sequence 15: never read by score()
+    want = oracle.align_all(frames, offsets, pct, *pens, workers=8)
+    assert np.isnan(want).any() and np.isfinite(want).any()
+    got = gpu_align_all(ctx, frames, offsets, 13, pct, *pens)
+    _assert_same_bits_or_nan(got, want)
+    # the flag is per batch: a finite batch on the same context goes back to the fast kernels, unflagged
+    from audio_pattern_discovery_amd.alignments import Batch
+    nf = C.c_int(-1)
+    b = Batch(ctx, frames, offsets, 13)
+    apd.check(apd.lib().apd_batch_nonfinite(ctx.handle, b.handle, C.byref(nf)), ctx.handle)
+    assert nf.value == 1
+    clean, off2 = synth.make_sequences(20, 40, 13, seed=31, jitter=9)
+    b2 = Batch(ctx, clean, off2, 13)
+    apd.check(apd.lib().apd_batch_nonfinite(ctx.handle, b2.handle, C.byref(nf)), ctx.handle)
+    assert nf.value == 0
+
+
+def test_a_shortened_launch_is_reported_not_zero_filled(ctx, oracle, apd):
+    """Every slab is poisoned with NaN before the alignment launches and the unpack writes every matrix entry: tiles that a
+    launch failed to process (here: fault injection drops the last 2 tiles of every kernel class) surface as NaN in the
+    matrix and as APD_ERR_INCOMPLETE -- the reference would leave silent 0.0 rows (alignments.rs:64-66)."""
+    from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
+    from audio_pattern_discovery_amd.discovery import Discovery
+    n = 80
+    frames, offsets = synth.make_sequences(n, 50, 13, seed=77)
+    want = oracle.align_all(frames, offsets, 0.0625, workers=8)
+    w = AlignmentWorkers.new([NDSequence(s) for s in synth.split(frames, offsets)], ctx)
+    ctx.set_fault_injection(2)
+    try:
+        with pytest.raises(apd.ApdError) as e:
+            w.align_all(Discovery(warping_band_percentage=0.0625))
+    finally:
+        ctx.set_fault_injection(0)
+    assert e.value.status == apd.APD_ERR_INCOMPLETE
+    got = w.result.reshape(n, n).copy()
+    off = ~np.eye(n, dtype=bool)
+    assert np.isnan(got).any() and not np.any(got[off] == 0.0)            # poison, not zeros
+    ok = ~np.isnan(got)
+    assert_parity(got[ok], want[ok])                                      # what was written is right
+    assert np.all(np.diag(got) == 0.0)
+    # the asynchronous entry points report through apd_synchronize, once
+    import torch
+    from audio_pattern_discovery_amd.alignments import Batch
+    b = Batch(ctx, frames, offsets, 13)
+    cfg = Discovery(warping_band_percentage=0.0625).align_config()
+    out = torch.zeros(n * n, dtype=torch.float32, device="cuda")
+    ctx.set_fault_injection(1)
+    apd.check(apd.lib().apd_align_all_device_async(ctx.handle, b.handle, C.byref(cfg), C.c_void_p(out.data_ptr())), ctx.handle)
+    ctx.set_fault_injection(0)
+    with pytest.raises(apd.ApdError) as e2:
+        ctx.synchronize()
+    assert e2.value.status == apd.APD_ERR_INCOMPLETE
+    ctx.synchronize()                                                     # reported once, then clear
+    # and a healthy run afterwards is complete and right
+    assert_parity(w.align_all(Discovery(warping_band_percentage=0.0625)).reshape(n, n), want)
+
+
+def test_batch_refill_keeps_plans_and_takes_new_values(ctx, oracle, apd):
+    import torch
+    from audio_pattern_discovery_amd.alignments import Batch
+    from audio_pattern_discovery_amd.discovery import Discovery
+    n = 40
+    f1, offsets = synth.make_sequences(n, 70, 13, seed=5)
+    f2 = (f1[::-1] * np.float32(1.5)).copy()                              # other values, same lengths
+    cfg = Discovery(warping_band_percentage=0.0625).align_config()
+    L = apd.lib()
+    b = Batch(ctx, f1, offsets, 13)
+    out = torch.empty(n * n, dtype=torch.float32, device="cuda")
+    apd.check(L.apd_align_all_device_async(ctx.handle, b.handle, C.byref(cfg), C.c_void_p(out.data_ptr())), ctx.handle)
+    ctx.synchronize()
+    assert_parity(out.cpu().numpy().reshape(n, n), oracle.align_all(f1, offsets, 0.0625, workers=8))
+    d_f2 = torch.from_numpy(f2).cuda()
+    apd.check(L.apd_batch_refill(ctx.handle, b.handle, C.c_void_p(d_f2.data_ptr()), 1), ctx.handle)
+    apd.check(L.apd_align_all_device_async(ctx.handle, b.handle, C.byref(cfg), C.c_void_p(out.data_ptr())), ctx.handle)
+    ctx.synchronize()
+    assert_parity(out.cpu().numpy().reshape(n, n), oracle.align_all(f2, offsets, 0.0625, workers=8))
+    f3 = f1.copy()
+    f3[11, 3] = np.nan                                                    # a refill re-evaluates the non-finite flag
+    apd.check(L.apd_batch_refill(ctx.handle, b.handle, f3.ctypes.data_as(C.POINTER(C.c_float)), 0), ctx.handle)
+    apd.check(L.apd_align_all_device_async(ctx.handle, b.handle, C.byref(cfg), C.c_void_p(out.data_ptr())), ctx.handle)
+    ctx.synchronize()
+    _assert_same_bits_or_nan(out.cpu().numpy().reshape(n, n), oracle.align_all(f3, offsets, 0.0625, workers=8))
+
+
+# ---- the multi-GPU entry points on the one GPU a test box has ---------------------------------------------------------
+
+def test_align_all_multi_one_device_equals_align_all(ctx, oracle, apd):
+    """apd_align_all_multi with n_devices = 1: ncclCommInitAll, the in-place all-gather of one slab, unpack -- the same bits as
+    apd_align_all, and RCCL reports one rank."""
+    from audio_pattern_discovery_amd import sharding
+    from audio_pattern_discovery_amd.discovery import Discovery
+    frames, offsets = synth.make_sequences(70, 60, 13, seed=4)
+    cfg = Discovery(warping_band_percentage=0.0625).align_config()
+    single = gpu_align_all(ctx, frames, offsets, 13, 0.0625)
+    multi, seen = sharding.align_all_multi([0], frames, offsets, 13, cfg)
+    assert seen == 1
+    assert np.array_equal(multi.view(np.uint32), single.view(np.uint32))
+    assert_parity(multi, oracle.align_all(frames, offsets, 0.0625, workers=8))
+    with pytest.raises(apd.ApdError):
+        sharding.align_all_multi([0, 0], frames, offsets, 13, cfg)         # two ranks on one device
+
+
+def test_sharded_async_through_a_library_owned_communicator(ctx, oracle, apd):
+    """One process per GPU form with world = 1: unique id -> apd_comm_create -> apd_align_all_sharded_async (tiles, ncclAllGather
+    on the context's stream, unpack) equals apd_align_all_device_async bit for bit; apd_all_gather_async moves data."""
+    import torch
+    from audio_pattern_discovery_amd import sharding
+    from audio_pattern_discovery_amd.alignments import Batch
+    from audio_pattern_discovery_amd.discovery import Discovery
+    n = 70
+    frames, offsets = synth.make_sequences(n, 60, 13, seed=4)
+    cfg = Discovery(warping_band_percentage=0.0625).align_config()
+    comm = sharding.Comm(ctx, sharding.Comm.unique_id(), 0, 1)
+    assert comm.count() == 1 and comm.rank() == 0
+    b = Batch(ctx, frames, offsets, 13)
+    a = torch.empty(n * n, dtype=torch.float32, device="cuda")
+    c = torch.empty(n * n, dtype=torch.float32, device="cuda")
+    comm.align_all_sharded_async(b.handle, cfg, a.data_ptr())
+    apd.check(apd.lib().apd_align_all_device_async(ctx.handle, b.handle, C.byref(cfg), C.c_void_p(c.data_ptr())), ctx.handle)
+    ctx.synchronize()
+    assert torch.equal(a, c)
+    assert_parity(a.cpu().numpy().reshape(n, n), oracle.align_all(frames, offsets, 0.0625, workers=8))
+    src = torch.arange(1000, dtype=torch.float32, device="cuda")
+    dst = torch.zeros(1000, dtype=torch.float32, device="cuda")
+    apd.check(apd.lib().apd_all_gather_async(ctx.handle, comm.handle, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), 1000), ctx.handle)
+    ctx.synchronize()
+    assert torch.equal(src, dst)
+    comm.close()
