@@ -115,6 +115,9 @@ namespace {
 // ---------------------------------------------------------------------------------------- UPGMA
 
 struct Cand { float l; uint32_t idp, idq, sp, sq; };
+// one segment of a long chain (see "the new cluster's row and column of S"): the predicted running sum at its start, the
+// exponent the map was computed under (0: no valid map) and the map S -> S + (S odd ? a1 : a0)
+struct SegRes { float predicted; uint32_t es, a0, a1, pack, pad0, pad1, pad2; };   // pack: offset of the segment's contiguous copy, or ~0
 
 __device__ __forceinline__ bool better(const Cand &a, const Cand &b)
 {
@@ -141,6 +144,15 @@ struct UpgmaState {
     uint32_t *last_sq;        // slot that died in the latest merge
     apd_cluster_op *ops;      // [n]
     uint32_t *n_ops;
+    float *R;                 // [n][n] R[x][slot]: approximate sum of d[x][y] over the members y of the cluster in `slot`
+    uint32_t *item_start;     // [2 n + 1] first work item of every chain of the current merge
+    uint32_t *item_count;     // [2 n] work items of every chain
+    float *packed;            // contiguous copies of the segments the commit pass is likely to re-walk (nullptr: off)
+    uint32_t *pack_used;      // bump allocator of `packed`, reset per merge
+    uint32_t pack_capacity;   // floats
+    const float *dT;          // [n][n] transposed copy of d (nullptr: off)
+    SegRes *seg;              // [max_items] segment results of the current merge
+    uint32_t *n_items;
     uint32_t *done;           // set once the loop condition of clustering.rs:104 fails
     float threshold;
     uint32_t n;
@@ -254,82 +266,520 @@ __global__ __launch_bounds__(1024) void upgma_merge_kernel(UpgmaState st)
     }
 }
 
-// Row and column of the cluster created by the latest merge, summed exactly as linkage() does
-// (clustering.rs:157-169): x ascending, y ascending, ONE f32 accumulator -- the order is the contract, so the sum
-// cannot be a tree.  One wavefront per (other cluster, direction): the 64 lanes gather 64 distances at a time, then
-// the accumulator walks them in order (v_readlane + add), ~100x faster than one thread chasing dependent loads.
-__global__ __launch_bounds__(256) void upgma_update_kernel(UpgmaState st)
+// ---- the exact-order f32 sum, evaluated in parallel -------------------------------------------------------------------
+// linkage() (clustering.rs:157-169) adds |Cp| * |Cq| distances into ONE f32 accumulator, x ascending, y ascending; every
+// add rounds, so the order is part of the result and a tree sum would change bits (and with them which of two nearly
+// tied cluster pairs merges first).  The chain is evaluated exactly, yet in parallel:
+//
+// While the running sum s stays inside one binade [2^e, 2^(e+1)), s = S * ulp with S an integer in [2^23, 2^24) and
+// ulp = 2^(e-23).  Adding x >= 0 gives fl(s + x) = RNE((S + x / ulp)) * ulp: with x / ulp = X + f (X integer, 0 <= f < 1),
+// S' = S + X + (f > 1/2) + (f == 1/2 and S + X odd).  So one element acts on S as  S -> S + A[S mod 2]  with two integer
+// offsets (A[0], A[1]) that differ only on an exact half-way tie.  Such maps are closed under composition,
+//      (F then G)[p] = F[p] + G[(p + F[p]) mod 2],
+// and composition is associative: a lane composes its own run of consecutive elements, a 64-lane prefix scan composes the
+// lanes in order, and S advances by up to 64 * kRun elements per step with integer arithmetic only.  The scan also tells
+// WHERE the sum first reaches 2^24 (leaves the binade): everything before that lane is committed, that lane's elements
+// are added one by one with real f32 adds (which handles the change of ulp, however many binades the sum jumps), and the
+// walk resumes behind it in the new binade.  A sum of n like-sized terms changes binade ~log2(n) times, so almost every
+// step is the parallel one.  Elements that are negative, NaN or -0.0 (penalties <= 0 can produce them), and sums that are
+// zero, subnormal, negative or non-finite, take the literal path: 64 gathered values added one by one (v_readlane + add).
+// The result is the reference's bit pattern in every case; tests/test_gpu_clustering.py compares bits against the CPU
+// oracle on matrices up to N = 4500, including tie-laden integer matrices, +INF blocks and NaN entries.
+namespace exact {
+
+constexpr uint32_t kCap = 1u << 26;              // saturation of the offsets: anything >= 2^24 already means "left the binade"
+
+struct Fn { uint32_t a0, a1; };                  // S -> S + (S odd ? a1 : a0)
+
+__device__ __forceinline__ Fn compose(const Fn f, const Fn g)   // f first, then g
 {
-    const uint32_t sp = *st.last_sp;
-    if (sp == 0xFFFFFFFFu || *st.done != 0) return;                      // nothing merged, or no further arg-min will run
-    const uint32_t nl = *st.n_live;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    const uint32_t c = wave >> 1, dir = wave & 1u;
-    if (c >= nl) return;
-    const uint32_t s = st.live[c];
-    if (s == sp) return;
-    const uint32_t *lx = st.pool + st.mstart[dir ? s : sp], *ly = st.pool + st.mstart[dir ? sp : s];
-    const uint32_t cx = st.mcount[dir ? s : sp], cy = st.mcount[dir ? sp : s];
-    float acc = 0.0f;
-    const uint64_t total = (uint64_t)cx * cy;
-    if (total < (1ull << 32)) {
-        // the (x, y) pairs in linkage()'s order are one linear sequence e = a * cy + b: 64 at a time are gathered (lane = e & 63),
-        // kPre chunks ahead of the adds so that the gather latency hides behind them; a chunk is padded with +0.0, which the
-        // accumulator absorbs exactly, so every chunk is the same 64 unrolled readlane + add steps.
-        constexpr int kPre = 8;
-        const uint32_t tot = (uint32_t)total;
-        auto fetch = [&](uint32_t e0) __attribute__((always_inline)) -> float {
-            const uint32_t e = e0 + lane;
-            if (e0 >= tot || e >= tot) return 0.0f;
-            const uint32_t a = e / cy, b = e - a * cy;
-            return st.d[(uint64_t)lx[a] * st.n + ly[b]];
-        };
-        float buf[kPre];
-#pragma unroll
-        for (int k = 0; k < kPre; ++k) buf[k] = fetch((uint32_t)k * 64u);
-        for (uint64_t e0 = 0; e0 < total; e0 += 64ull * kPre) {
-#pragma unroll
-            for (int k = 0; k < kPre; ++k) {
-                const uint64_t ek = e0 + 64ull * k;
-                if (ek < total) {                                        // wave-uniform
-                    const float v = buf[k];
-                    const uint64_t nx = ek + 64ull * kPre;
-                    buf[k] = (nx < total) ? fetch((uint32_t)nx) : 0.0f;
-#pragma unroll
-                    for (int t = 0; t < 64; ++t)
-                        acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t));
-                }
-            }
+    Fn h;
+    h.a0 = min(f.a0 + ((f.a0 & 1u) ? g.a1 : g.a0), kCap);
+    h.a1 = min(f.a1 + ((f.a1 & 1u) ? g.a0 : g.a1), kCap);       // parity after f from an odd S is (1 + f.a1) mod 2
+    return h;
+}
+
+// The map of one element x (raw bits xb of a finite, non-negative float) on the integer mantissa of a sum whose biased
+// exponent is es (>= 1).  An element in the sum's own binade or above returns kCap: the sum leaves the binade.
+__device__ __forceinline__ Fn element(uint32_t xb, uint32_t es)
+{
+    uint32_t ex = xb >> 23, mx = xb & 0x7FFFFFu;
+    if (ex) mx |= 0x800000u; else ex = 1u;       // subnormal x: no hidden bit, exponent of the smallest normal
+    Fn f;
+    if (ex >= es) { f.a0 = f.a1 = (mx == 0u) ? 0u : kCap; return f; }   // x == +0.0 is the identity
+    const uint32_t sh = min(es - ex, 25u);       // >= 25: x < ulp / 2, the add is absorbed
+    const uint32_t X = mx >> sh, r = mx & ((1u << sh) - 1u), half = 1u << (sh - 1u);
+    const uint32_t up = r > half ? 1u : 0u, tie = r == half ? 1u : 0u;
+    f.a0 = X + (up | (tie & (X & 1u)));          // S even: S + X has the parity of X
+    f.a1 = X + (up | (tie & (~X & 1u)));         // S odd
+    return f;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Fn dpp_fn(const Fn v)  // lanes without a source (or outside ROW_MASK) get the identity map
+{
+    Fn r;
+    r.a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.a0, CTRL, ROW_MASK, 0xf, false);
+    r.a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.a1, CTRL, ROW_MASK, 0xf, false);
+    return r;
+}
+
+// inclusive prefix composition over the 64 lanes, lane order = element order
+__device__ __forceinline__ Fn wave_scan(Fn v)
+{
+    v = compose(dpp_fn<0x111, 0xf>(v), v);       // row_shr:1
+    v = compose(dpp_fn<0x112, 0xf>(v), v);       // row_shr:2
+    v = compose(dpp_fn<0x114, 0xf>(v), v);       // row_shr:4
+    v = compose(dpp_fn<0x118, 0xf>(v), v);       // row_shr:8   -> prefix inside each row of 16
+    v = compose(dpp_fn<0x142, 0xa>(v), v);       // row_bcast:15 into rows 1, 3
+    v = compose(dpp_fn<0x143, 0xc>(v), v);       // row_bcast:31 into rows 2, 3
+    return v;
+}
+
+__device__ __forceinline__ float readlane_f(float v, int lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// Where a chain's elements come from: gathered from the distance matrix (element e = a * cy + b is d[lx[a] * n + ly[b]]),
+// or from the packed copy a segment wavefront left behind (contiguous, so that re-walking a segment costs 1/16 of the
+// cache lines of the gather).
+struct GatherSrc {
+    const float *m; uint64_t sx, sy;                                    // element (a, b) is m[lx[a] * sx + ly[b] * sy]
+    const uint32_t *lx; uint32_t cx; const uint32_t *ly; uint32_t cy;
+    template <int K>
+    __device__ __forceinline__ void load_run(uint64_t first, uint64_t total, float (&x)[K]) const
+    {
+        uint32_t a = 0, b = 0;
+        if (first < total) {
+            if (total <= 0xFFFFFFFFull) { a = (uint32_t)first / cy; b = (uint32_t)first - a * cy; }          // wave-uniform: the cheap division
+            else { a = (uint32_t)(first / cy); b = (uint32_t)(first - (uint64_t)a * cy); }
         }
-    } else {
-        for (uint32_t a = 0; a < cx; ++a) {
-            const float *row = st.d + (uint64_t)lx[a] * st.n;
-            for (uint32_t b0 = 0; b0 < cy; b0 += 64) {
-                const uint32_t cnt = min(64u, cy - b0);
-                const float v = (lane < cnt) ? row[ly[b0 + lane]] : 0.0f;
-                for (uint32_t t = 0; t < cnt; ++t)
-                    acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t));
-            }
+        const float *row = m + (uint64_t)lx[min(a, cx - 1)] * sx;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const bool live = first + j < total;
+            x[j] = live ? row[(uint64_t)ly[b] * sy] : 0.0f;             // padding: +0.0 is the identity
+            if (live && ++b == cy) { b = 0; ++a; row = m + (uint64_t)lx[min(a, cx - 1)] * sx; }
         }
     }
-    if (lane != 0) return;
-    if (dir) {
-        st.S[(uint64_t)s * st.n + sp] = acc;
-        // row s: its cached best pair survives unless it pointed at one of the two merged slots; the new entry may beat it
-        const Cand old = st.rbest[s];
-        if (old.sq == sp || old.sq == *st.last_sq) st.rscan[s] = 1;
-        else {
-            const Cand cnd{acc / (st.size[s] * st.size[sp]), st.id[s], st.id[sp], s, sp};
-            if (better(cnd, old)) st.rbest[s] = cnd;
+    __device__ __forceinline__ float load_one(uint64_t e, uint64_t total) const
+    {
+        uint32_t a, b;
+        if (total <= 0xFFFFFFFFull) { a = (uint32_t)e / cy; b = (uint32_t)e - a * cy; }
+        else { a = (uint32_t)(e / cy); b = (uint32_t)(e - (uint64_t)a * cy); }
+        return m[(uint64_t)lx[a] * sx + (uint64_t)ly[b] * sy];
+    }
+};
+struct PackedSrc {
+    const float *p;                                                     // p[e]: element e of the chain
+    template <int K>
+    __device__ __forceinline__ void load_run(uint64_t first, uint64_t total, float (&x)[K]) const
+    {
+#pragma unroll
+        for (int j = 0; j < K; ++j) x[j] = first + j < total ? p[first + j] : 0.0f;
+    }
+    __device__ __forceinline__ float load_one(uint64_t e, uint64_t) const { return p[e]; }
+};
+
+// Elements [pos, total) of a chain are added, in order, into the one f32 accumulator `s` -- by one wavefront; every lane
+// returns the same value.  (pos = 0, s = +0.0, total = cx * cy is linkage()'s whole sum.)  kRun = consecutive elements per
+// lane and step: 64 * kRun elements advance per step, kRun loads per lane are in flight at a time.
+template <int kRun, typename Src>
+__device__ float ordered_walk(const Src src, uint32_t lane, uint64_t pos, uint64_t total, float s)
+{
+    while (pos < total) {
+        const uint32_t sb = __builtin_bit_cast(uint32_t, s);
+        const uint32_t es = sb >> 23;                                   // sign + exponent: 1..254 <=> positive, normal, finite
+        const bool fast = es >= 1u && es <= 254u;
+        if ((fast || sb == 0x7F800000u) && total - pos > 64) {          // a remainder of <= 64 elements: one literal round is cheaper
+            float x[kRun];                                              // this lane's run: elements pos + lane * kRun + j
+            src.template load_run<kRun>(pos + (uint64_t)lane * kRun, total, x);
+            bool bad = false;                                           // negative (incl. -0.0) or NaN: not a map on S
+            Fn f{0u, 0u};
+#pragma unroll
+            for (int j = 0; j < kRun; ++j) {
+                const uint32_t xb = __builtin_bit_cast(uint32_t, x[j]);
+                bad |= xb > 0x7F800000u;
+                f = compose(f, element(xb, es));
+            }
+            if (bad) f.a0 = f.a1 = kCap;                                // sends the walk into this lane's run, one real add at a time
+            const uint64_t step = min<uint64_t>(total - pos, 64ull * kRun);
+            if (!fast) {
+                // s == +INF stays +INF under non-negative finite or infinite terms; a NaN or a negative term (-INF) ends that
+                const unsigned long long bm = __ballot(bad);
+                if (bm == 0ull) { pos += step; continue; }
+                const int L = __builtin_ctzll(bm);
+#pragma unroll
+                for (int j = 0; j < kRun; ++j) s = s + readlane_f(x[j], L);
+                pos = min<uint64_t>(pos + (uint64_t)(L + 1) * kRun, total);
+                continue;
+            }
+            const Fn pre = wave_scan(f);
+            const uint32_t S = (sb & 0x7FFFFFu) | 0x800000u;
+            const uint32_t adv = (S & 1u) ? pre.a1 : pre.a0;            // S advances by this much up to and including this lane
+            const unsigned long long leaves = __ballot(S + adv >= (1u << 24));
+            if (leaves == 0ull) {
+                const uint32_t Sn = S + (uint32_t)__builtin_amdgcn_readlane((int)adv, 63);
+                s = __builtin_bit_cast(float, (es << 23) | (Sn & 0x7FFFFFu));
+                pos += step;
+                continue;
+            }
+            const int L = __builtin_ctzll(leaves);                      // first lane whose run takes the sum out of the binade
+            if (L > 0) {
+                const uint32_t Sn = S + (uint32_t)__builtin_amdgcn_readlane((int)adv, L - 1);
+                s = __builtin_bit_cast(float, (es << 23) | (Sn & 0x7FFFFFu));
+            }
+#pragma unroll
+            for (int j = 0; j < kRun; ++j) s = s + readlane_f(x[j], L);  // real adds: any rounding regime, any jump
+            pos = min<uint64_t>(pos + (uint64_t)(L + 1) * kRun, total);
+        } else {
+            // literal path (s is zero, subnormal, negative or NaN, or the chain is about to end): 64 elements, one real add each
+            const uint64_t e = pos + lane;
+            const float v = e < total ? src.load_one(e, total) : 0.0f;
+            const uint32_t cnt = (uint32_t)min<uint64_t>(64, total - pos);
+            if (cnt == 64) {
+#pragma unroll
+                for (int t = 0; t < 64; ++t) s = s + readlane_f(v, t);
+            } else {
+                for (uint32_t t = 0; t < cnt; ++t) s = s + readlane_f(v, (int)t);
+            }
+            pos += cnt;
         }
-    } else st.S[(uint64_t)sp * st.n + s] = acc;
+    }
+    return s;
+}
+
+// The map of elements [begin, end) of the chain on the integer mantissa of a sum whose biased exponent is `es` and stays
+// `es` throughout: every lane composes its own contiguous share (no cross-lane traffic until one ordered reduction at the
+// end).  {kCap, kCap} if an element cannot be expressed (negative, NaN, or large enough to leave the binade by itself).
+// The elements are also written to pack[0 .. end - begin) for whoever has to re-walk the segment.
+__device__ Fn segment_fn(const GatherSrc src, uint32_t lane, uint64_t begin, uint64_t end, uint32_t es, float *__restrict__ pack)
+{
+    const uint64_t len = end - begin, share = (len + 63) / 64;
+    uint64_t e = begin + share * lane;
+    const uint64_t stop = min<uint64_t>(e + share, end);
+    Fn f{0u, 0u};
+    bool bad = false;
+    constexpr int kUnroll = 8;                                           // loads of 8 elements in flight per lane
+    while (e < stop) {
+        float x[kUnroll];
+        src.load_run<kUnroll>(e, stop, x);
+        const uint32_t cnt = (uint32_t)min<uint64_t>(kUnroll, stop - e);
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+            const uint32_t xb = __builtin_bit_cast(uint32_t, x[j]);
+            bad |= xb > 0x7F800000u;
+            f = compose(f, element(xb, es));                             // padding (+0.0) is the identity
+            if (pack && (uint32_t)j < cnt) pack[(e - begin) + j] = x[j];
+        }
+        e += cnt;
+    }
+    if (bad) f.a0 = f.a1 = kCap;
+    f = wave_scan(f);                                                    // lane 63 holds the composition of all shares, in order
+    Fn out;
+    out.a0 = (uint32_t)__builtin_amdgcn_readlane((int)f.a0, 63);
+    out.a1 = (uint32_t)__builtin_amdgcn_readlane((int)f.a1, 63);
+    return out;
+}
+
+}  // namespace exact
+
+// ---- the new cluster's row and column of S -----------------------------------------------------------------------------
+// After a merge, S[k][r] and S[r][k] are re-summed for every other live cluster r: 2 (n_live - 1) chains of |Ck| * |Cr|
+// elements each.  The longest of them is the critical path of a merge (10^6 elements once two clusters of ~1000 members
+// face each other), so a long chain is cut into SEGMENTS of whole rows (~kSegElems elements) that are evaluated by
+// different wavefronts at the same time -- speculatively, because a segment's integer map (exact::segment_fn) needs the
+// binade of the running sum at the segment's start.  That binade is predicted from R[x][slot], an approximate
+// (any-order) sum of d[x][y] over the members y of the cluster in `slot`, kept up to date per merge: the prefix of the
+// row sums estimates the running sum at every row boundary.  One wavefront per chain then walks the segments in order
+// with the TRUE sum: a segment whose assumed exponent matches and whose map keeps the sum inside the binade is applied in
+// O(1); any other segment (the first one, the ~log2(L) binade changes, a rare misprediction near a power of two, segments
+// with negative or NaN entries) is re-walked element by element from the true sum by exact::ordered_walk.  The result is
+// bit-identical to the sequential chain either way; the speculation only decides how fast it is reached.
+namespace {
+
+constexpr uint32_t kSegElems = 4096;             // target elements per segment
+constexpr uint32_t kLaneChain = 2048;            // a SINGLETON against a new cluster of up to this many members: one lane, the literal loop
+constexpr uint32_t kShortChain = 2 * kSegElems;  // other chains up to this length are walked whole by one wavefront
+
+struct Chain {
+    const uint32_t *lx, *ly;
+    uint32_t cx, cy;
+    uint32_t slot_y;        // slot of the cluster the inner index runs over (its column of R predicts the row sums)
+    uint32_t s, dir;        // the other cluster's slot; dir 0: S[sp][s], dir 1: S[s][sp]
+    uint32_t rps, nseg;     // rows per segment, segments (0: skipped chain, 1: walked whole)
+    bool lane_chain;        // a singleton's chain: summed by one lane of upgma_short_kernel; otherwise by the segment / commit kernels
+};
+
+__device__ __forceinline__ Chain get_chain(const UpgmaState &st, uint32_t w, uint32_t sp)
+{
+    Chain c{};
+    c.dir = w & 1u;
+    c.s = st.live[w >> 1];
+    if (c.s == sp) return c;                                             // nseg = 0
+    const uint32_t sx = c.dir ? c.s : sp, sy = c.dir ? sp : c.s;
+    c.lx = st.pool + st.mstart[sx]; c.ly = st.pool + st.mstart[sy];
+    c.cx = st.mcount[sx]; c.cy = st.mcount[sy];
+    c.slot_y = sy;
+    const uint64_t len = (uint64_t)c.cx * c.cy;
+    if (len <= kLaneChain && (c.dir ? c.cx : c.cy) == 1u) { c.rps = c.cx; c.nseg = 1; c.lane_chain = true; return c; }
+    if (len <= kShortChain) { c.rps = c.cx; c.nseg = 1; return c; }
+    c.rps = c.cy >= kSegElems ? 1u : kSegElems / c.cy;
+    c.nseg = (c.cx + c.rps - 1) / c.rps;
+    return c;
+}
+
+// S[sp][s] chains (dir 0) walk rows of d; S[s][sp] chains (dir 1) would walk columns of d restricted to the new cluster --
+// one float per cache line, lines that no other chain uses.  They read the transposed copy instead, where the same
+// elements lie in the new cluster's |Ck| rows: the chains of neighbouring clusters then share cache lines in both directions.
+__device__ __forceinline__ exact::GatherSrc chain_src(const UpgmaState &st, const Chain &c)
+{
+    if (c.dir == 0 || st.dT == nullptr) return exact::GatherSrc{st.d, st.n, 1, c.lx, c.cx, c.ly, c.cy};
+    return exact::GatherSrc{st.dT, 1, st.n, c.lx, c.cx, c.ly, c.cy};
+}
+
+// what lane 0 does with a finished sum (the tail of the former one-kernel update)
+__device__ __forceinline__ void finish_chain(const UpgmaState &st, const Chain &c, uint32_t sp, float acc)
+{
+    if (c.dir) {
+        st.S[(uint64_t)c.s * st.n + sp] = acc;
+        // row s: its cached best pair survives unless it pointed at one of the two merged slots; the new entry may beat it
+        const Cand old = st.rbest[c.s];
+        if (old.sq == sp || old.sq == *st.last_sq) st.rscan[c.s] = 1;
+        else {
+            const Cand cnd{acc / (st.size[c.s] * st.size[sp]), st.id[c.s], st.id[sp], c.s, sp};
+            if (better(cnd, old)) st.rbest[c.s] = cnd;
+        }
+    } else st.S[(uint64_t)sp * st.n + c.s] = acc;
+}
+
+}  // namespace
+
+// Wide: R[x][sp] += R[x][sq] (the merged cluster's approximate row sums), and every chain's number of work items.
+__global__ __launch_bounds__(256) void upgma_count_kernel(UpgmaState st)
+{
+    const uint32_t sp = *st.last_sp;
+    if (sp == 0xFFFFFFFFu || *st.done != 0) return;
+    const uint32_t sq = *st.last_sq, n = st.n, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        float *r = st.R + (uint64_t)t * n;
+        r[sp] = r[sp] + r[sq];
+    }
+    if (t < 2u * *st.n_live) { const Chain c = get_chain(st, t, sp); st.item_count[t] = c.lane_chain ? 0u : c.nseg; }   // singletons' chains: upgma_short_kernel
+    if (t == 0) *st.pack_used = 0;
+}
+
+// One workgroup: item_start[w] = first work item of chain w (exclusive scan of the chains' item counts).
+__global__ __launch_bounds__(1024) void upgma_plan_kernel(UpgmaState st)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t sp = *st.last_sp;
+    if (sp == 0xFFFFFFFFu || *st.done != 0) { if (threadIdx.x == 0) *st.n_items = 0; return; }
+    const uint32_t chains = 2u * *st.n_live;
+    const uint32_t per = (chains + blockDim.x - 1) / blockDim.x, w0 = threadIdx.x * per, w1 = min(w0 + per, chains);
+    uint32_t sum = 0;
+    for (uint32_t w = w0; w < w1; ++w) sum += st.item_count[w];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < blockDim.x; o <<= 1) {                      // inclusive scan of the per-thread totals
+        const uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+    for (uint32_t w = w0; w < w1; ++w) { st.item_start[w] = run; run += st.item_count[w]; }
+    if (threadIdx.x == blockDim.x - 1) { st.item_start[chains] = part[threadIdx.x]; *st.n_items = part[threadIdx.x]; }
+}
+
+// One wavefront per segmented chain: the predicted running sum at every segment start, from the row sums in R.
+__global__ __launch_bounds__(256) void upgma_predict_kernel(UpgmaState st)
+{
+    const uint32_t sp = *st.last_sp;
+    if (sp == 0xFFFFFFFFu || *st.done != 0) return;
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (w >= 2u * *st.n_live) return;
+    const Chain c = get_chain(st, w, sp);
+    if (c.nseg < 2) return;
+    SegRes *res = st.seg + st.item_start[w];
+    float base = 0.0f;
+    for (uint32_t a0 = 0; a0 < c.cx; a0 += 64) {
+        const uint32_t a = a0 + lane;
+        const float v = a < c.cx ? st.R[(uint64_t)c.lx[a] * st.n + c.slot_y] : 0.0f;
+        float incl = v;                                                  // inclusive scan over the lanes (any rounding will do)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(incl, o); if ((int)lane >= o) incl += t; }
+        if (a < c.cx && a % c.rps == 0) {
+            const float before = base + (incl - v);                      // sum of the rows before row a
+            res[a / c.rps].predicted = before;
+        }
+        base += __shfl(incl, 63);
+    }
+}
+
+// A singleton against the new cluster (most chains of a merge, |Ck| terms each): ONE LANE per chain runs linkage()'s loop
+// literally -- one f32 accumulator, members of the new cluster ascending -- so nothing about the order needs proving.  The
+// 64 lanes of a wavefront hold 64 neighbouring singletons in one direction.  In both directions the matrix ROW of element i
+// is member i of the NEW cluster (a row of d for S[sp][s], a row of the transposed copy for S[s][sp]) and the column is the
+// singleton: the row sequence is wave-uniform (the member list goes through scalar loads), every load instruction reads
+// neighbouring floats of one row -- whole cache lines instead of one line per float -- and 32 loads are in flight per lane.
+__global__ __launch_bounds__(256) void upgma_short_kernel(UpgmaState st)
+{
+    const uint32_t sp = *st.last_sp;
+    if (sp == 0xFFFFFFFFu || *st.done != 0) return;
+    const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const uint32_t nl = *st.n_live, dir = wid & 1u, cidx = (wid >> 1) * 64u + lane;
+    if ((wid >> 1) * 64u >= nl) return;
+    Chain c{};
+    if (cidx < nl) c = get_chain(st, 2u * cidx + dir, sp);
+    const bool active = c.lane_chain;
+    if (__ballot(active) == 0ull) return;
+    // element i is M[ck[i] * rs + own * cs]
+    const uint32_t K = st.mcount[sp];
+    const uint32_t *ck = st.pool + st.mstart[sp];                       // wave-uniform
+    const bool transposed = dir == 1 && st.dT != nullptr;
+    const float *M = transposed ? st.dT : st.d;
+    const uint64_t rs = (dir == 1 && !transposed) ? 1 : st.n, cs = (dir == 1 && !transposed) ? st.n : 1;
+    const uint64_t col = active ? (uint64_t)(dir ? c.lx[0] : c.ly[0]) * cs : 0;
+    float s = 0.0f;                                                      // distance = 0.0 (clustering.rs:154)
+    constexpr int kAhead = 32;
+    for (uint32_t i0 = 0; i0 < K; i0 += kAhead) {
+        float x[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const uint32_t r = ck[min(i0 + u, K - 1)];                  // uniform address: a scalar load
+            x[u] = M[(uint64_t)r * rs + col];
+        }
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) if (i0 + u < K) s = s + x[u];   // distance += d[x][y] (:162), in order
+    }
+    if (active) finish_chain(st, c, sp, s);
+}
+
+// Work items: a short chain is walked whole and finished; a segment of a long chain gets its integer map under the
+// predicted exponent.  Items are dealt to wavefronts in groups of 32 consecutive items per XCD (blocks b and b + 8 share an
+// XCD and its L2): the chains of neighbouring clusters read neighbouring floats of the same cache lines, so a line comes
+// in from HBM / Infinity Cache once per group instead of once per XCD.  (Placement is a speed matter only.)
+// A segment is also copied to `packed`, contiguously, when the commit pass is likely to re-walk it: the predicted sum
+// changes binade inside it or sits within 2^-10 of a power of two.
+__global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
+{
+    const uint32_t sp = *st.last_sp;
+    if (sp == 0xFFFFFFFFu || *st.done != 0) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n_items = *st.n_items, chains = 2u * *st.n_live;
+    const uint32_t xcd = blockIdx.x & 7u, v = (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6);   // v-th wavefront of this XCD
+    const uint32_t groups_per_round = (gridDim.x >> 3) * 4u / 32u * 8u;                        // gridDim.x is a multiple of 64
+    for (uint32_t g = (v >> 5) * 8u + xcd; (uint64_t)g * 32u < n_items; g += groups_per_round) {
+        const uint32_t item = g * 32u + (v & 31u);
+        if (item >= n_items) break;
+        uint32_t lo = 0, hi = chains;                                    // chain of this item: largest w with item_start[w] <= item
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (st.item_start[mid] <= item) lo = mid; else hi = mid; }
+        const uint32_t w = lo;
+        const Chain c = get_chain(st, w, sp);
+        const exact::GatherSrc src = chain_src(st, c);
+        if (c.nseg == 1) {
+            const float acc = exact::ordered_walk<8>(src, lane, 0, (uint64_t)c.cx * c.cy, 0.0f);
+            if (lane == 0) finish_chain(st, c, sp, acc);
+            continue;
+        }
+        const uint32_t j = item - st.item_start[w];
+        SegRes *res = st.seg + item;
+        const uint32_t pb = __builtin_bit_cast(uint32_t, res->predicted), es = pb >> 23;
+        exact::Fn f{exact::kCap, exact::kCap};
+        uint32_t pack_off = 0xFFFFFFFFu;
+        if (es >= 1u && es <= 254u) {
+            const uint64_t begin = (uint64_t)j * c.rps * c.cy, end = min<uint64_t>(begin + (uint64_t)c.rps * c.cy, (uint64_t)c.cx * c.cy);
+            const uint32_t len = (uint32_t)(end - begin);
+            // will the commit pass re-walk this segment?  (the next segment's prediction is this segment's predicted end)
+            const uint32_t nb = j + 1 < c.nseg ? __builtin_bit_cast(uint32_t, res[1].predicted) : 0xFFFFFFFFu;
+            const uint32_t frac = pb & 0x7FFFFFu, nfrac = nb & 0x7FFFFFu;
+            const bool risky = (nb >> 23) != es || frac < (1u << 13) || nfrac > 0x7FFFFFu - (1u << 13);
+            if (risky && st.packed) {
+                if (lane == 0) {
+                    pack_off = atomicAdd(st.pack_used, len);
+                    if ((uint64_t)pack_off + len > st.pack_capacity) pack_off = 0xFFFFFFFFu;
+                }
+                pack_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)pack_off);
+            }
+            f = exact::segment_fn(src, lane, begin, end, es, pack_off != 0xFFFFFFFFu ? st.packed + pack_off : nullptr);
+        }
+        if (lane == 0) {
+            res->es = (f.a0 >= exact::kCap || f.a1 >= exact::kCap) ? 0u : es;
+            res->a0 = f.a0; res->a1 = f.a1;
+            res->pack = pack_off;
+        }
+    }
+}
+
+// One wavefront per segmented chain: the true sum through the segments, in order.
+__global__ __launch_bounds__(256) void upgma_commit_kernel(UpgmaState st)
+{
+    const uint32_t sp = *st.last_sp;
+    if (sp == 0xFFFFFFFFu || *st.done != 0) return;
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (w >= 2u * *st.n_live) return;
+    const Chain c = get_chain(st, w, sp);
+    if (c.nseg < 2) return;
+    const SegRes *res = st.seg + st.item_start[w];
+    const uint64_t total = (uint64_t)c.cx * c.cy, seg_len = (uint64_t)c.rps * c.cy;
+    float s = 0.0f;
+    for (uint32_t j0 = 0; j0 < c.nseg; j0 += 64) {
+        SegRes mine{};                                                   // lane t holds segment j0 + t
+        if (j0 + lane < c.nseg) mine = res[j0 + lane];
+        const uint32_t cnt = min(64u, c.nseg - j0);
+        for (uint32_t t = 0; t < cnt; ++t) {
+            const uint32_t es_j = (uint32_t)__builtin_amdgcn_readlane((int)mine.es, (int)t);
+            const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)mine.a0, (int)t);
+            const uint32_t a1 = (uint32_t)__builtin_amdgcn_readlane((int)mine.a1, (int)t);
+            const uint32_t sb = __builtin_bit_cast(uint32_t, s);
+            if (es_j != 0u && (sb >> 23) == es_j) {
+                const uint32_t S = (sb & 0x7FFFFFu) | 0x800000u;
+                const uint32_t Sn = S + ((S & 1u) ? a1 : a0);
+                if (Sn < (1u << 24)) { s = __builtin_bit_cast(float, (es_j << 23) | (Sn & 0x7FFFFFu)); continue; }
+            }
+            // re-walk this segment from the true sum: from the packed copy if its wavefront got as far as making one
+            const uint64_t begin = (uint64_t)(j0 + t) * seg_len, end = min<uint64_t>(begin + seg_len, total);
+            const uint32_t pack_off = (uint32_t)__builtin_amdgcn_readlane((int)mine.pack, (int)t);
+            if (pack_off != 0xFFFFFFFFu)                                  // PackedSrc indexes by chain element: rebase to the segment
+                s = exact::ordered_walk<16>(exact::PackedSrc{st.packed + pack_off - begin}, lane, begin, end, s);
+            else
+                s = exact::ordered_walk<16>(chain_src(st, c), lane, begin, end, s);
+        }
+    }
+    if (lane == 0) finish_chain(st, c, sp, s);
 }
 
 __global__ void upgma_init_S_kernel(UpgmaState st)
 {
     const uint64_t nn = (uint64_t)st.n * st.n;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nn; e += (uint64_t)gridDim.x * blockDim.x)
-        st.S[e] = 0.0f + st.d[e];                                         // distance = 0.0 + d[x][y] (:154,162)
+    {
+        const float v = st.d[e];
+        st.S[e] = 0.0f + v;                                               // distance = 0.0 + d[x][y] (:154,162)
+        st.R[e] = v;                                                      // singleton clusters: slot y holds instance y
+    }
+}
+
+// dT[y][x] = d[x][y], 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void upgma_transpose_kernel(const float *__restrict__ d, float *__restrict__ dT, uint32_t n)
+{
+    __shared__ float tile[32][33];
+    const uint32_t tiles = (n + 31) / 32;
+    for (uint64_t t = blockIdx.x; t < (uint64_t)tiles * tiles; t += gridDim.x) {
+        const uint32_t ty = (uint32_t)(t / tiles), tx = (uint32_t)(t % tiles), lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+        for (uint32_t r = ly; r < 32; r += 8) {
+            const uint32_t y = ty * 32 + r, x = tx * 32 + lx;
+            tile[r][lx] = (y < n && x < n) ? d[(uint64_t)y * n + x] : 0.0f;
+        }
+        __syncthreads();
+        for (uint32_t r = ly; r < 32; r += 8) {
+            const uint32_t y = tx * 32 + r, x = ty * 32 + lx;
+            if (y < n && x < n) dT[(uint64_t)y * n + x] = tile[lx][r];
+        }
+        __syncthreads();
+    }
 }
 
 __global__ void upgma_init_kernel(UpgmaState st)
@@ -383,11 +833,18 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     const size_t bytes_S = nn * sizeof(float), bytes_f = (size_t)n * sizeof(float), bytes_u = (size_t)n * sizeof(uint32_t);
     const size_t bytes_lists = ((size_t)n * (n + 1) / 2 + n) * sizeof(uint32_t);    // every merged list is appended once
     const size_t bytes_d = distances_on_device ? 0 : bytes_S;
-    const size_t total = bytes_S + bytes_d + bytes_lists + bytes_f + 5 * bytes_u + (size_t)n * sizeof(Cand) +
-                         (size_t)n * sizeof(apd_cluster_op) + 256;
+    // segments of one merge: sum over chains of ceil(rows / rows-per-segment) <= 2 (sum of chain lengths) / kSegElems + chains,
+    // and the chains of one merge hold 2 |Ck| (n - |Ck|) <= n^2 / 2 elements
+    const size_t max_items = (size_t)(nn / kSegElems) + 2 * (size_t)n + 64;
+    const size_t bytes_items = (2 * (size_t)n + 2) * sizeof(uint32_t), bytes_seg = max_items * sizeof(SegRes);
+    // packed copies of the segments the commit pass is likely to re-walk (a few per chain); when it is full, they are gathered again
+    const size_t bytes_packed = (size_t)std::min<uint64_t>(nn / 8 + 65536, 1ull << 30) * sizeof(float);
+    const size_t total = 3 * bytes_S + bytes_d + bytes_lists + bytes_f + 5 * bytes_u + (size_t)n * sizeof(Cand) +
+                         (size_t)n * sizeof(apd_cluster_op) + 2 * bytes_items + bytes_seg + bytes_packed + 1024;
     HIP_TRY(ctx, hipMalloc((void **)&pool, total));
     size_t off = 0;
     st.S = (float *)(pool + off); off += bytes_S;
+    st.R = (float *)(pool + off); off += bytes_S;
     float *d_copy = (float *)(pool + off); off += bytes_d;
     st.pool = (uint32_t *)(pool + off); off += bytes_lists;
     st.size = (float *)(pool + off); off += bytes_f;
@@ -399,8 +856,18 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     st.rbest = (Cand *)(pool + off); off += (size_t)n * sizeof(Cand);
     st.ops = (apd_cluster_op *)(pool + off); off += (size_t)n * sizeof(apd_cluster_op);
     off = (off + 63) & ~(size_t)63;
+    st.seg = (SegRes *)(pool + off); off += bytes_seg;
+    st.item_start = (uint32_t *)(pool + off); off += bytes_items;
+    st.item_count = (uint32_t *)(pool + off); off += bytes_items;
+    off = (off + 255) & ~(size_t)255;
+    st.packed = (float *)(pool + off); off += bytes_packed;
+    st.pack_capacity = (uint32_t)(bytes_packed / sizeof(float));
+    float *d_T = (float *)(pool + off); off += bytes_S;
+    st.dT = d_T;
+    off = (off + 63) & ~(size_t)63;
     st.n_live = (uint32_t *)(pool + off); st.n_ops = st.n_live + 1; st.done = st.n_live + 2;
-    st.pool_used = st.n_live + 3; st.last_sp = st.n_live + 4; st.last_sq = st.n_live + 5;
+    st.pool_used = st.n_live + 3; st.last_sp = st.n_live + 4; st.last_sq = st.n_live + 5; st.n_items = st.n_live + 6;
+    st.pack_used = st.n_live + 7;
     auto fail = [&](int rc) { hipFree(pool); return rc; };
     if (distances_on_device) st.d = distances;
     else {
@@ -418,17 +885,27 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
 
     hipLaunchKernelGGL(upgma_init_S_kernel, dim3((unsigned)std::min<uint64_t>((nn + 255) / 256, 8192)), dim3(256), 0, ctx->stream, st);
     hipLaunchKernelGGL(upgma_init_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, st);
+    hipLaunchKernelGGL(upgma_transpose_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)((n + 31) / 32) * ((n + 31) / 32), 16384)), dim3(256), 0,
+                       ctx->stream, st.d, d_T, n);
     uint32_t host_state[3] = {n, 0, 0};                                   // n_live, n_ops, done
-    // The merge loop is launch-bound (three short dependent launches per merge): a batch of merges is captured once into a
+    // The merge loop is launch-bound (six short dependent launches per merge): a batch of merges is captured once into a
     // hipGraph and replayed until the device-side `done` flag rises; kernels launched after that return immediately.
     const uint32_t batch = 64;
+    const uint32_t chain_blocks = (2 * n + 3) / 4;                        // one wavefront per (other cluster, direction)
+    const uint32_t segment_blocks = (std::min(chain_blocks, 8192u) + 63u) / 64u * 64u;   // groups of 32 wavefronts per XCD
+    const uint32_t short_blocks = (2 * ((n + 63) / 64) + 3) / 4;         // one wavefront per (64 clusters, direction)
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     auto enqueue_batch = [&]() {
         for (uint32_t b = 0; b < batch; ++b) {
             hipLaunchKernelGGL(upgma_rowmin_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream, st);
             hipLaunchKernelGGL(upgma_merge_kernel, dim3(1), dim3(1024), 0, ctx->stream, st);
-            hipLaunchKernelGGL(upgma_update_kernel, dim3((2 * n + 3) / 4), dim3(256), 0, ctx->stream, st);
+            hipLaunchKernelGGL(upgma_count_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, ctx->stream, st);
+            hipLaunchKernelGGL(upgma_plan_kernel, dim3(1), dim3(1024), 0, ctx->stream, st);
+            hipLaunchKernelGGL(upgma_short_kernel, dim3(short_blocks), dim3(256), 0, ctx->stream, st);
+            hipLaunchKernelGGL(upgma_predict_kernel, dim3(chain_blocks), dim3(256), 0, ctx->stream, st);
+            hipLaunchKernelGGL(upgma_segment_kernel, dim3(segment_blocks), dim3(256), 0, ctx->stream, st);
+            hipLaunchKernelGGL(upgma_commit_kernel, dim3(chain_blocks), dim3(256), 0, ctx->stream, st);
         }
     };
     auto drop_graph = [&]() { if (exec) hipGraphExecDestroy(exec); if (graph) hipGraphDestroy(graph); exec = nullptr; graph = nullptr; };

@@ -85,6 +85,8 @@ def make_distance_matrix(n, kind="points", seed=0):
     * "ties":   small integers -- exact linkage ties everywhere, asymmetric,
     * "inf":    two blocks at +INF from each other (length-1 sequences score +INF, alignments.rs:122) plus one +INF row,
     * "nan":    5 % NaN entries (percentile drops them, numerics.rs:127-130; a NaN linkage never wins),
+    * "big":    three tight clusters -- late merges face clusters of hundreds of members (linkage chains of 10^5 terms),
+    * "neg":    i.i.d. U(-1, 1): negative "distances" (what non-positive penalties can produce),
     * "uniform": i.i.d. U(0, 1)."""
     rng = np.random.default_rng(seed)
     if kind == "points":
@@ -94,6 +96,13 @@ def make_distance_matrix(n, kind="points", seed=0):
         for k in range(3):
             d += (pts[:, None, k].astype(np.float32) - pts[None, :, k].astype(np.float32)) ** 2
         d = np.sqrt(d) * (1.0 + 0.05 * rng.random((n, n), dtype=np.float32))
+    elif kind == "big":
+        centres = rng.standard_normal((3, 24)) * 3
+        pts = (centres[rng.integers(0, 3, n)] + rng.standard_normal((n, 24)) * (0.2 + 0.8 * rng.random((n, 1)))).astype(np.float32)
+        sq = (pts * pts).sum(1)
+        d = np.sqrt(np.maximum(sq[:, None] + sq[None, :] - 2.0 * (pts @ pts.T), 0.0)) * (1.0 + 0.02 * rng.random((n, n), dtype=np.float32))
+    elif kind == "neg":
+        d = rng.random((n, n), dtype=np.float32) * 2 - 1
     elif kind == "ties":
         d = rng.integers(1, 7, size=(n, n)).astype(np.float32)
     elif kind == "inf":

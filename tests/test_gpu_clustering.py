@@ -135,10 +135,12 @@ def test_end_to_end_align_then_cluster(ctx, oracle):
 
 @pytest.mark.parametrize("n,kind,perc", [(300, "points", 0.05), (300, "ties", 0.6), (700, "nan", 0.5), (1100, "points", 0.05),
                                          (1100, "inf", 0.9), (1500, "ties", 0.4), (2048, "points", 0.05), (4096, "points", 0.05),
-                                         (4500, "uniform", 0.02), (4500, "ties", 0.5)])
+                                         (4500, "uniform", 0.02), (4500, "ties", 0.5), (1500, "big", 0.9), (3000, "big", 0.3),
+                                         (1200, "neg", 0.7), (2400, "inf", 0.95), (2000, "ties", 0.97), (1800, "nan", 0.9)])
 def test_large_matrices_match_fast_oracle(ctx, oracle, n, kind, perc):
     """Device UPGMA at sizes the literal O(n^4) oracle cannot reach (row-minimum loops beyond one workgroup's width, the
-    arg-min over more than 1024 rows, grid-stride rows beyond 4096, long exact-order chains), against the cached-linkage
+    arg-min over more than 1024 rows, grid-stride rows beyond 4096, exact-order chains of 10^5..10^6 terms that are cut into
+    speculatively evaluated segments, with binade changes, +INF, NaN and negative entries inside them), against the cached-linkage
     CPU oracle that tests/test_oracle.py proves equal to the literal one.  Merge sequence (merge_i, merge_j, into, kind),
     roots and threshold identical; linkages bit for bit (the tolerance asked is 1e-5)."""
     from audio_pattern_discovery_amd.clustering import AgglomerativeClustering

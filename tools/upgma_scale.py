@@ -1,4 +1,5 @@
-"""Scale check of apd_clustering on a resident N x N matrix (run on the GPU box): python tools/upgma_scale.py 16384"""
+"""Scale check of apd_clustering on a resident N x N matrix (run on the GPU box):
+python tools/upgma_scale.py N [percentile] [centres] [chain|blob] [dims]"""
 import ctypes as C
 import sys
 import time
@@ -12,9 +13,10 @@ from audio_pattern_discovery_amd import _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 perc = float(sys.argv[2]) if len(sys.argv) > 2 else 0.05
 torch.manual_seed(0)
-x = torch.randn(n, 8, device="cuda")
+dims = int(sys.argv[5]) if len(sys.argv) > 5 else 8                 # 64+: distances concentrate, as DTW costs of long noisy takes do
+x = torch.randn(n, dims, device="cuda")
 n_centers = int(sys.argv[3]) if len(sys.argv) > 3 else 64          # 16: the family structure of bench.py's cfg 5 audio
-centers = torch.randn(n_centers, 8, device="cuda") * 4
+centers = torch.randn(n_centers, dims, device="cuda") * 4
 if len(sys.argv) > 4 and sys.argv[4] == "chain":                    # member k of a family sits at noise radius ~ k / 16: clusters grow one by one
     k = torch.arange(n, device="cuda")
     x = x * (0.02 + 2.0 * (k // n_centers).float()[:, None] / (n / n_centers)) + centers[k % n_centers]
