@@ -42,6 +42,25 @@ class ClusterOp(C.Structure):
                 ("distance", C.c_float), ("operation", C.c_uint32)]
 
 
+class MatView(C.Structure):
+    """apd_mat_view: where a Mat { flat, cols } (numerics.rs:171-174) lies in a bincode image."""
+    _fields_ = [("offset", C.c_uint64), ("len", C.c_uint64), ("cols", C.c_uint64)]
+
+
+class AutoEncoderView(C.Structure):
+    """apd_autoencoder_view (neural.rs:13-19)."""
+    _fields_ = [("w_encode", MatView), ("w_decode", MatView), ("b_encode", MatView), ("b_decode", MatView)]
+
+
+class DiscoveryC(C.Structure):
+    """apd_discovery (discovery.rs:7-26)."""
+    _fields_ = [("dft_win", C.c_uint64), ("dft_step", C.c_uint64), ("ceps_filter", C.c_uint64), ("vat_moving", C.c_uint64),
+                ("vat_percentile", C.c_float), ("vat_min_len", C.c_uint64), ("alignment_workers", C.c_uint64),
+                ("clustering_percentile", C.c_float), ("warping_band_percentage", C.c_float), ("insertion_penalty", C.c_float),
+                ("deletion_penalty", C.c_float), ("match_penalty", C.c_float), ("auto_encoder", C.c_uint64),
+                ("learning_rate", C.c_float), ("epochs", C.c_uint64), ("epoch_drop", C.c_float), ("drop", C.c_float)]
+
+
 class ApdError(RuntimeError):
     def __init__(self, status, detail=""):
         self.status = status
@@ -110,6 +129,12 @@ SYMBOLS = [
                                      _u32p]),
     ("apd_cepstrum", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _vp, _u64p,
                                _u32p]),
+    ("apd_autoencoder_parse", C.c_int, [_vp, C.c_uint64, C.POINTER(AutoEncoderView)]),
+    ("apd_autoencoder_copy", C.c_int, [_vp, C.POINTER(MatView), _f32p]),
+    ("apd_autoencoder_serialize", C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_uint32, C.c_uint32, _vp, C.c_uint64, _u64p]),
+    ("apd_discovery_parse_toml", C.c_int, [C.c_char_p, C.POINTER(DiscoveryC)]),
+    ("apd_dendrograms", C.c_int, [C.POINTER(ClusterOp), C.c_uint32, _u32p, C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, _vp,
+                                  C.c_uint64, _u64p, _u32p, _u32p]),
 ]
 
 _lib = None

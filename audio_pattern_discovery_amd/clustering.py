@@ -74,20 +74,23 @@ def percentile(x, perc, ctx=None):
 
 
 def dendrograms(operations, clusters, labels):
-    """The bracket strings reporting.rs:135-169 builds for TikZ-qtree, one per root that was merged at least once:
-    leaf i is rendered as labels[i] (the reference puts an \\includegraphics reference there), node k as
-    "[.k [<left> <right> ] ]".  Roots never merged are skipped, as the reference does (reporting.rs:200).
+    """The bracket strings reporting.rs:135-169 builds for TikZ-qtree (apd_dendrograms), one per root that was merged at
+    least once: leaf i is rendered as labels[i] (the reference puts an \\includegraphics reference there, reporting.rs:211-221),
+    node k as "[.k [<left> <right> ] ]".  Roots never merged are skipped, as the reference does (reporting.rs:200).
     Lets a run be diffed against the reference's output/ (SURVEY.md 8(f) item 4)."""
-    results = {}
-    for op in operations:
-        i, j, k = op.merge_i, op.merge_j, op.into
-        if op.operation == Merge.Sequence2Sequence:
-            left, right = labels[i], labels[j]
-        elif op.operation == Merge.Sequence2Cluster:
-            left, right = labels[i], results[j]
-        elif op.operation == Merge.Cluster2Sequence:
-            left, right = results[i], labels[j]
-        else:
-            left, right = results[i], results[j]
-        results[k] = "[.%d [%s %s ] ]" % (k, left, right)
-    return {c: results[c] for c in sorted(clusters) if c in results}
+    ops = (_lib.ClusterOp * max(len(operations), 1))()
+    for t, o in enumerate(operations):
+        ops[t] = _lib.ClusterOp(o.merge_i, o.merge_j, o.into, o.distance, int(o.operation))
+    roots = np.array(sorted(clusters), dtype=np.uint32)
+    lab = (C.c_char_p * max(len(labels), 1))(*[str(v).encode() for v in labels])
+    which = np.zeros(len(roots) + 1, dtype=np.uint32)
+    n_bytes, n_strings = C.c_uint64(0), C.c_uint32(0)
+    u32p = C.POINTER(C.c_uint32)
+    L = _lib.lib()
+    _lib.check(L.apd_dendrograms(ops, len(operations), roots.ctypes.data_as(u32p), len(roots), lab, len(labels), None, 0,
+                                 C.byref(n_bytes), which.ctypes.data_as(u32p), C.byref(n_strings)))
+    buf = C.create_string_buffer(n_bytes.value + 1)
+    _lib.check(L.apd_dendrograms(ops, len(operations), roots.ctypes.data_as(u32p), len(roots), lab, len(labels), buf, n_bytes.value,
+                                 C.byref(n_bytes), which.ctypes.data_as(u32p), C.byref(n_strings)))
+    parts = buf.raw[:n_bytes.value].split(b"\0")[:n_strings.value]
+    return {int(roots[which[i]]): parts[i].decode() for i in range(n_strings.value)}

@@ -29,22 +29,14 @@ class Discovery:
 
     @staticmethod
     def from_toml(file):
-        """discovery.rs:29-36.  Flat `key = value  # comment` files only (what the reference ships)."""
-        kinds = {f.name: f.type for f in fields(Discovery)}
-        vals = {}
+        """discovery.rs:28-36 through apd_discovery_parse_toml.  Flat `key = value  # comment` files only (what the
+        reference ships); a missing, duplicate or unknown key is an error, as with serde."""
         with open(file) as fp:                      # a missing file raises, like .expect() at :31
-            for line in fp:
-                line = line.split("#", 1)[0].strip()
-                if not line or "=" not in line:
-                    continue
-                k, v = [t.strip() for t in line.split("=", 1)]
-                if k not in kinds:
-                    raise KeyError("unknown Discovery key %r" % k)
-                vals[k] = int(v) if kinds[k] in (int, "int") else float(v)
-        missing = [k for k in kinds if k not in vals]
-        if missing:
-            raise KeyError("missing Discovery keys: %s" % missing)   # serde would fail the same way
-        return Discovery(**vals)
+            text = fp.read()
+        d = _lib.DiscoveryC()
+        if _lib.lib().apd_discovery_parse_toml(text.encode(), C.byref(d)) != _lib.APD_OK:
+            raise KeyError("not a complete Discovery.toml (missing, duplicate, unknown or ill-typed key)")
+        return Discovery(**{f.name: getattr(d, f.name) for f in fields(Discovery)})
 
     def align_config(self):
         return _lib.AlignConfig(self.warping_band_percentage, self.insertion_penalty,

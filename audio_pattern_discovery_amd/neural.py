@@ -4,7 +4,6 @@ reference's `output/encoder/auto_encoder.bin` (bincode 1.x default configuration
 lengths as u64, f32 as 4 bytes; struct fields in declaration order -- neural.rs:13-19, numerics.rs:171-174), so the
 weights of a real reference run can be fed to apd_encode."""
 import ctypes as C
-import struct
 
 import numpy as np
 
@@ -32,25 +31,18 @@ class AutoEncoder:
 
     @staticmethod
     def from_bytes(buf):
-        """bincode::deserialize::<AutoEncoder> (neural.rs:30-36): w_encode, w_decode, b_encode, b_decode, each a
-        Mat { flat: Vec<f32>, cols: usize }."""
-        mats, pos = [], 0
-        for _ in range(4):
-            if pos + 8 > len(buf):
-                raise ValueError("truncated bincode AutoEncoder")
-            (n,) = struct.unpack_from("<Q", buf, pos)
-            pos += 8
-            if pos + 4 * n + 8 > len(buf):
-                raise ValueError("truncated bincode AutoEncoder")
-            flat = np.frombuffer(buf, dtype="<f4", count=n, offset=pos).astype(np.float32)
-            pos += 4 * n
-            (cols,) = struct.unpack_from("<Q", buf, pos)
-            pos += 8
-            if cols == 0 or n % cols:
-                raise ValueError("Mat with %d values and %d columns" % (n, cols))
-            mats.append(Mat(flat, cols))
-        if pos != len(buf):
-            raise ValueError("trailing bytes after bincode AutoEncoder")
+        """bincode::deserialize::<AutoEncoder> (neural.rs:30-36) through apd_autoencoder_parse / apd_autoencoder_copy:
+        w_encode, w_decode, b_encode, b_decode, each a Mat { flat: Vec<f32>, cols: usize }."""
+        buf = bytes(buf)
+        view = _lib.AutoEncoderView()
+        raw = C.create_string_buffer(buf, len(buf))
+        if _lib.lib().apd_autoencoder_parse(raw, len(buf), C.byref(view)) != _lib.APD_OK:
+            raise ValueError("not a bincode AutoEncoder (truncated, trailing bytes or inconsistent Mat shapes)")
+        mats = []
+        for mv in (view.w_encode, view.w_decode, view.b_encode, view.b_decode):
+            flat = np.empty(mv.len, dtype=np.float32)
+            _lib.check(_lib.lib().apd_autoencoder_copy(raw, C.byref(mv), flat.ctypes.data_as(C.POINTER(C.c_float))))
+            mats.append(Mat(flat, mv.cols))
         return AutoEncoder(mats[0], mats[2], mats[1], mats[3])
 
     @staticmethod
@@ -58,14 +50,22 @@ class AutoEncoder:
         with open(file, "rb") as fp:
             return AutoEncoder.from_bytes(fp.read())
 
-    def to_bytes(self):                       # bincode::serialize (neural.rs:39-44)
-        out = b""
+    def to_bytes(self):                       # bincode::serialize (neural.rs:39-44) through apd_autoencoder_serialize
+        mats = []
         for m in (self.w_encode, self.w_decode, self.b_encode, self.b_decode):
             if m is None:
                 raise ValueError("decoder half missing: cannot serialise")
-            m = m if isinstance(m, Mat) else Mat(m, np.asarray(m).shape[-1])
-            out += struct.pack("<Q", m.flat.size) + m.flat.astype("<f4").tobytes() + struct.pack("<Q", m.cols)
-        return out
+            mats.append(m if isinstance(m, Mat) else Mat(m, np.asarray(m).shape[-1]))
+        latent, d_in = mats[0].cols, mats[0].rows()
+        f32p = C.POINTER(C.c_float)
+        ptrs = [m.flat.ctypes.data_as(f32p) for m in mats]
+        n = C.c_uint64(0)
+        _lib.check(_lib.lib().apd_autoencoder_serialize(None, None, None, None, d_in, latent, None, 0, C.byref(n)))
+        out = C.create_string_buffer(n.value)
+        if (mats[1].flat.size, mats[2].flat.size, mats[3].flat.size) != (d_in * latent, latent, d_in):
+            raise ValueError("AutoEncoder matrices have inconsistent shapes")
+        _lib.check(_lib.lib().apd_autoencoder_serialize(ptrs[0], ptrs[1], ptrs[2], ptrs[3], d_in, latent, out, n.value, C.byref(n)))
+        return out.raw
 
     def save_file(self, file):                # neural.rs:39-44
         with open(file, "wb") as fp:

@@ -241,6 +241,44 @@ int apd_interesting_ranges(apd_context *ctx, const float *frames, uint64_t t, ui
                            float perc, uint64_t min_len, int on_device, uint64_t *ranges, uint64_t capacity,
                            uint64_t *n_ranges);
 
+/* ---- formats either side of the path (host only, no context needed) ------------------------------------------------ */
+/* AutoEncoder::from_file / save_file (src/neural.rs:30-44): the bincode 1.x image of
+ *   struct AutoEncoder { w_encode, w_decode, b_encode, b_decode: Mat }  (neural.rs:13-19)
+ *   struct Mat { flat: Vec<f32>, cols: usize }                             (numerics.rs:171-174)
+ * i.e. four times { u64 length, length x f32, u64 cols }, little-endian.  apd_autoencoder_parse checks the image (sizes,
+ * shapes D x L / L x D / 1 x L / 1 x D, no trailing bytes) and says where each matrix lies; apd_autoencoder_copy reads one
+ * out (byte order handled); w_encode and b_encode are what apd_encode takes. */
+typedef struct apd_mat_view { uint64_t offset /* byte offset of flat[0] */, len /* values */, cols; } apd_mat_view;
+typedef struct apd_autoencoder_view { apd_mat_view w_encode, w_decode, b_encode, b_decode; } apd_autoencoder_view;
+int apd_autoencoder_parse(const void *bytes, uint64_t n_bytes, apd_autoencoder_view *view);
+int apd_autoencoder_copy(const void *bytes, const apd_mat_view *mat, float *out /* mat->len floats */);
+/* out == NULL: *n_bytes = size of the image.  w_encode: [d_in][latent], w_decode: [latent][d_in], b_*: [latent], [d_in]. */
+int apd_autoencoder_serialize(const float *w_encode, const float *w_decode, const float *b_encode, const float *b_decode,
+                              uint32_t d_in, uint32_t latent, void *out, uint64_t capacity, uint64_t *n_bytes);
+
+/* Discovery (src/discovery.rs:7-26) and Discovery::from_toml (:28-36) on the text of project/config/Discovery.toml: flat
+ * `key = value  # comment` lines; every field exactly once, unknown keys refused, integers for the usize fields. */
+typedef struct apd_discovery {
+    uint64_t dft_win, dft_step, ceps_filter, vat_moving;
+    float vat_percentile;
+    uint64_t vat_min_len, alignment_workers;
+    float clustering_percentile, warping_band_percentage, insertion_penalty, deletion_penalty, match_penalty;
+    uint64_t auto_encoder;
+    float learning_rate;
+    uint64_t epochs;
+    float epoch_drop, drop;
+} apd_discovery;
+int apd_discovery_parse_toml(const char *text, apd_discovery *out);
+
+/* Templates::dendrograms (src/reporting.rs:135-169), the strings only: for every root that some op made, the TikZ-qtree
+ * bracket string "[.k [<left> <right> ] ]" with leaves rendered as labels[leaf] (the reference puts its image_ref there,
+ * reporting.rs:211-221) -- NUL-terminated, concatenated in the order of `roots`; which_root[i] = index into roots of
+ * string i (roots never merged have none, reporting.rs:200).  out == NULL: sizes only.  The LaTeX / file output of :171-203
+ * is presentation and stays with the caller. */
+int apd_dendrograms(const apd_cluster_op *ops, uint32_t n_ops, const uint32_t *roots, uint32_t n_roots,
+                    const char *const *labels, uint32_t n_labels, char *out, uint64_t capacity, uint64_t *n_bytes,
+                    uint32_t *which_root, uint32_t *n_strings);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,7 +3,10 @@
 // Errors that are panics in the reference (zero-length sequence, percentile index out of range) throw apd::Error.
 #pragma once
 #include <cstdint>
+#include <fstream>
+#include <iterator>
 #include <limits>
+#include <map>
 #include <set>
 #include <stdexcept>
 #include <string>
@@ -47,6 +50,64 @@ struct NDSequence {
     std::size_t len() const { return n_bins ? frames.size() / n_bins : 0; }         // :152-154
 };
 
+// numerics.rs:171-174
+struct Mat {
+    std::vector<float> flat;
+    std::size_t cols = 0;
+    std::size_t rows() const { return cols ? flat.size() / cols : 0; }
+};
+
+// neural.rs:12-71: the weight file and the forward pass (training is outside the accelerated path)
+struct AutoEncoder {
+    Mat w_encode, w_decode, b_encode, b_decode;
+    std::size_t n_latent() const { return b_encode.cols; }                          // :22-24
+    static AutoEncoder from_bytes(const std::vector<unsigned char> &buf)             // bincode::deserialize, :34
+    {
+        apd_autoencoder_view v;
+        check(apd_autoencoder_parse(buf.data(), buf.size(), &v));
+        AutoEncoder nn;
+        const apd_mat_view *views[4] = {&v.w_encode, &v.w_decode, &v.b_encode, &v.b_decode};
+        Mat *mats[4] = {&nn.w_encode, &nn.w_decode, &nn.b_encode, &nn.b_decode};
+        for (int k = 0; k < 4; ++k) {
+            mats[k]->flat.resize(views[k]->len);
+            mats[k]->cols = views[k]->cols;
+            check(apd_autoencoder_copy(buf.data(), views[k], mats[k]->flat.data()));
+        }
+        return nn;
+    }
+    static AutoEncoder from_file(const std::string &file)                            // :30-36
+    {
+        std::ifstream in(file, std::ios::binary);
+        if (!in) throw Error(APD_ERR_INVALID_ARG, "cannot open " + file);            // File::open(file)? -> DiscoveryError::IO
+        const std::vector<unsigned char> buf((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        return from_bytes(buf);
+    }
+    void save_file(const std::string &file) const                                    // :39-44
+    {
+        const uint32_t latent = (uint32_t)w_encode.cols, d_in = (uint32_t)w_encode.rows();
+        uint64_t n = 0;
+        check(apd_autoencoder_serialize(nullptr, nullptr, nullptr, nullptr, d_in, latent, nullptr, 0, &n));
+        std::vector<unsigned char> buf(n);
+        check(apd_autoencoder_serialize(w_encode.flat.data(), w_decode.flat.data(), b_encode.flat.data(), b_decode.flat.data(), d_in, latent,
+                                        buf.data(), buf.size(), &n));
+        std::ofstream out(file, std::ios::binary);
+        out.write((const char *)buf.data(), (std::streamsize)buf.size());
+        if (!out) throw Error(APD_ERR_INVALID_ARG, "cannot write " + file);
+    }
+    // AutoEncoder::predict on every frame of a sequence = NDSequence::encoded (neural.rs:55-71, spectrogram.rs:103-121)
+    NDSequence encoded(Context &ctx, const NDSequence &x) const
+    {
+        if (x.n_bins != w_encode.rows()) throw Error(APD_ERR_INVALID_ARG, "self.cols == other.rows()");   // numerics.rs:306
+        NDSequence out;
+        out.n_bins = n_latent();
+        out.audio_id = x.audio_id;
+        out.frames.resize(x.len() * out.n_bins);
+        check(apd_encode(ctx.get(), x.frames.data(), x.len(), (uint32_t)x.n_bins, w_encode.flat.data(), b_encode.flat.data(), (uint32_t)out.n_bins, 0,
+                         out.frames.data()), ctx.get());
+        return out;
+    }
+};
+
 // alignments.rs:77-83
 struct AlignmentParams {
     std::size_t warping_band;
@@ -54,11 +115,33 @@ struct AlignmentParams {
     static AlignmentParams default_for(std::size_t len) { return {len, 1.0f, 1.0f, 1.0f}; }   // :86-93
 };
 
-// discovery.rs:7-26 -- the fields this path reads
+// discovery.rs:7-26 -- every field of project/config/Discovery.toml (defaults: the shipped file)
 struct Discovery {
-    float warping_band_percentage = 1.0f, insertion_penalty = 1.0f, deletion_penalty = 1.0f, match_penalty = 1.0f;
+    std::size_t dft_win = 256, dft_step = 128, ceps_filter = 32, vat_moving = 15;
+    float vat_percentile = 0.95f;
+    std::size_t vat_min_len = 150;
     std::size_t alignment_workers = 4;      // accepted, unused: the GPU grid replaces the OS threads
     float clustering_percentile = 0.05f;
+    float warping_band_percentage = 1.0f, insertion_penalty = 1.0f, deletion_penalty = 1.0f, match_penalty = 1.0f;
+    std::size_t auto_encoder = 10;
+    float learning_rate = 0.1f;
+    std::size_t epochs = 25;
+    float epoch_drop = 5.0f, drop = 0.5f;
+    static Discovery from_toml(const std::string &file)                             // discovery.rs:28-36
+    {
+        std::ifstream in(file);
+        if (!in) throw Error(APD_ERR_INVALID_ARG, "Template file not found");        // .expect() at :31
+        const std::string text((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        apd_discovery d;
+        check(apd_discovery_parse_toml(text.c_str(), &d));                            // toml::from_str(..).unwrap() at :34
+        Discovery c;
+        c.dft_win = d.dft_win; c.dft_step = d.dft_step; c.ceps_filter = d.ceps_filter; c.vat_moving = d.vat_moving;
+        c.vat_percentile = d.vat_percentile; c.vat_min_len = d.vat_min_len; c.alignment_workers = d.alignment_workers;
+        c.clustering_percentile = d.clustering_percentile; c.warping_band_percentage = d.warping_band_percentage;
+        c.insertion_penalty = d.insertion_penalty; c.deletion_penalty = d.deletion_penalty; c.match_penalty = d.match_penalty;
+        c.auto_encoder = d.auto_encoder; c.learning_rate = d.learning_rate; c.epochs = d.epochs; c.epoch_drop = d.epoch_drop; c.drop = d.drop;
+        return c;
+    }
     apd_align_config config() const { return {warping_band_percentage, insertion_penalty, deletion_penalty, match_penalty}; }
     AlignmentParams alignment_params(std::size_t n_size) const                       // discovery.rs:38-45
     {
@@ -153,5 +236,29 @@ struct AgglomerativeClustering {
         return out;
     }
 };
+
+// Templates::dendrograms (reporting.rs:135-169), the strings: root id -> "[.k [<left> <right> ] ]" with leaf i rendered as
+// labels[i]; roots no op made are absent (reporting.rs:200).
+inline std::map<std::size_t, std::string> dendrograms(const std::vector<ClusteringOperation> &operations, const std::set<std::size_t> &clusters,
+                                                      const std::vector<std::string> &labels)
+{
+    std::vector<apd_cluster_op> ops;
+    for (const auto &o : operations) ops.push_back({(uint32_t)o.merge_i, (uint32_t)o.merge_j, (uint32_t)o.into, o.distance, (uint32_t)o.operation});
+    const std::vector<uint32_t> roots(clusters.begin(), clusters.end());
+    std::vector<const char *> lab;
+    for (const auto &l : labels) lab.push_back(l.c_str());
+    uint64_t bytes = 0;
+    uint32_t n_strings = 0;
+    std::vector<uint32_t> which(roots.size() + 1);
+    check(apd_dendrograms(ops.data(), (uint32_t)ops.size(), roots.data(), (uint32_t)roots.size(), lab.data(), (uint32_t)lab.size(), nullptr, 0, &bytes,
+                          which.data(), &n_strings));
+    std::vector<char> buf(bytes + 1);
+    check(apd_dendrograms(ops.data(), (uint32_t)ops.size(), roots.data(), (uint32_t)roots.size(), lab.data(), (uint32_t)lab.size(), buf.data(), bytes,
+                          &bytes, which.data(), &n_strings));
+    std::map<std::size_t, std::string> out;
+    const char *p = buf.data();
+    for (uint32_t i = 0; i < n_strings; ++i) { out[roots[which[i]]] = p; p += out[roots[which[i]]].size() + 1; }
+    return out;
+}
 
 }  // namespace apd

@@ -2,6 +2,9 @@
 // C++ mirror -- AlignmentWorkers::new -> align_all -> AgglomerativeClustering::clustering -> cluster_sets -- and prints
 // the results for tests/test_gpu_cpp_mirror.py to compare with the oracle.
 //   usage: harness <input.txt>    input: n dim pct ins del match perc, then per sequence: len, then len*dim floats
+//          harness <input.txt> <auto_encoder.bin> <Discovery.toml>   the same with the reference's on-disk artefacts: the
+//              parameters come from the TOML file, every sequence goes through AutoEncoder::from_file(..) -> encoded() first
+//              (main.rs:142-161), and the weight file is written back with save_file and compared byte for byte
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -26,6 +29,24 @@ int main(int argc, char **argv)
     }
     try {
         apd::Context ctx(0);
+        if (argc >= 4) {
+            cfg = apd::Discovery::from_toml(argv[3]);
+            std::printf("toml %zu %zu %zu %zu %.9g %zu %zu %.9g %.9g %.9g %.9g %.9g %zu %.9g %zu %.9g %.9g\n", cfg.dft_win, cfg.dft_step, cfg.ceps_filter,
+                        cfg.vat_moving, cfg.vat_percentile, cfg.vat_min_len, cfg.alignment_workers, cfg.clustering_percentile,
+                        cfg.warping_band_percentage, cfg.insertion_penalty, cfg.deletion_penalty, cfg.match_penalty, cfg.auto_encoder,
+                        cfg.learning_rate, cfg.epochs, cfg.epoch_drop, cfg.drop);
+            const apd::AutoEncoder nn = apd::AutoEncoder::from_file(argv[2]);
+            std::printf("latent %zu\n", nn.n_latent());
+            for (auto &s : seqs) s = nn.encoded(ctx, s);
+            std::printf("enc0");
+            for (float v : seqs[0].frames) std::printf(" %.9g", v);
+            std::printf("\n");
+            const std::string copy = std::string(argv[2]) + ".copy";
+            nn.save_file(copy);
+            std::ifstream a(argv[2], std::ios::binary), b(copy, std::ios::binary);
+            const std::string sa((std::istreambuf_iterator<char>(a)), std::istreambuf_iterator<char>()), sb((std::istreambuf_iterator<char>(b)), std::istreambuf_iterator<char>());
+            std::printf("roundtrip %d\n", (int)(sa == sb && !sa.empty()));
+        }
         apd::AlignmentWorkers workers(ctx, seqs);
         workers.align_all(cfg);
         std::printf("dist");
@@ -41,6 +62,9 @@ int main(int argc, char **argv)
             for (auto m : s) std::printf(" %zu", m);
             std::printf("\n");
         }
+        std::vector<std::string> labels;
+        for (std::size_t i = 0; i < n; ++i) labels.push_back("{img" + std::to_string(i) + "}");
+        for (const auto &kv : apd::dendrograms(res.first, res.second, labels)) std::printf("dendro %zu %s\n", kv.first, kv.second.c_str());
         apd::Alignment a(ctx);
         a.construct_alignment(seqs[0], seqs[1], cfg.alignment_params(std::max(seqs[0].len(), seqs[1].len())));
         std::printf("pair01 %.9g\n", a.score());

@@ -81,10 +81,22 @@ clustering_percentile   = 0.05
     f = tmp_path / "Discovery.toml"
     f.write_text(text)
     d = Discovery.from_toml(str(f))
-    assert d.dft_win == 256 and d.warping_band_percentage == 0.0625 and d.clustering_percentile == 0.05
-    (tmp_path / "bad.toml").write_text("dft_win = 1\n")
-    with pytest.raises(KeyError):
-        Discovery.from_toml(str(tmp_path / "bad.toml"))
+    assert d.dft_win == 256 and d.warping_band_percentage == 0.0625
+    assert d.clustering_percentile == np.float32(0.05) and d.vat_percentile == np.float32(0.95)     # the reference's fields are f32
+    assert (d.dft_step, d.ceps_filter, d.auto_encoder, d.epochs, d.vat_moving, d.vat_min_len, d.alignment_workers) == (128, 32, 10, 25, 15, 150, 4)
+    assert (d.learning_rate, d.epoch_drop, d.drop) == (np.float32(0.1), 5.0, 0.5)
+    for bad in ("dft_win = 1\n",                                        # 16 fields missing (serde: missing field)
+                text + "dft_win = 3\n",                                  # duplicate key
+                text + "colour = 3\n",                                   # unknown key
+                text.replace("dft_step      = 128", "dft_step      = 128.5"),   # a float where usize is wanted
+                text.replace("epochs        = 25", "epochs        = -25"),
+                text.replace("drop          = 0.5", "drop          = half")):
+        (tmp_path / "bad.toml").write_text(bad)
+        with pytest.raises(KeyError):
+            Discovery.from_toml(str(tmp_path / "bad.toml"))
+    # the file the reference ships parses (project/config/Discovery.toml, reproduced in SURVEY.md section 5: band 1.0, workers 4)
+    (tmp_path / "shipped.toml").write_text(text.replace("0.0625", "1.0       # sakoe shiba band"))
+    assert Discovery.from_toml(str(tmp_path / "shipped.toml")).warping_band_percentage == 1.0
     with pytest.raises(OSError):
         Discovery.from_toml(str(tmp_path / "missing.toml"))
 
@@ -154,3 +166,27 @@ def test_dendrogram_bracket_strings():
     out = dendrograms(ops, {6}, ["A", "B", "C", "D"])
     assert out == {6: "[.6 [[.5 [C [.4 [A B ] ] ] ] D ] ]"}
     assert dendrograms(ops[:1], {2, 3, 4}, ["A", "B", "C", "D"]) == {4: "[.4 [A B ] ]"}
+
+
+def test_dendrograms_equal_a_literal_replay_of_the_reference_loop(oracle, apd):
+    """apd_dendrograms expands each root on demand; the reference builds every intermediate string in a HashMap
+    (reporting.rs:142-169).  Both must give the same characters on real merge lists (oracle clustering of random batches)."""
+    from audio_pattern_discovery_amd.clustering import ClusteringOperation, Merge, dendrograms
+    for n, perc, seed in ((9, 0.3, 1), (30, 0.9, 2), (64, 0.6, 3), (5, 0.99, 4)):
+        d = synth.make_distance_matrix(n, "points" if seed % 2 else "ties", seed=seed)
+        ops, roots, _ = oracle.clustering(d, n, perc)
+        labels = ["{img%d}\n" % i for i in range(n)]
+        results = {}
+        for o in ops:                                                   # the reference's loop, literally
+            i, j, k = o["merge_i"], o["merge_j"], o["into"]
+            left = results[i] if o["operation"] in ("Cluster2Sequence", "Cluster2Cluster") else labels[i]
+            right = results[j] if o["operation"] in ("Sequence2Cluster", "Cluster2Cluster") else labels[j]
+            results[k] = "[.%d [%s %s ] ]" % (k, left, right)
+        want = {r: results[r] for r in roots if r in results}
+        mine = [ClusteringOperation(o["merge_i"], o["merge_j"], o["into"], o["distance"], Merge[o["operation"]]) for o in ops]
+        assert dendrograms(mine, set(roots), labels) == want
+    # an op that names a cluster no earlier op made: the reference's HashMap index panics
+    with pytest.raises(apd.ApdError):
+        dendrograms([ClusteringOperation(0, 7, 4, 0.1, Merge.Sequence2Cluster)], {4}, ["A", "B"])
+    with pytest.raises(apd.ApdError):
+        dendrograms([ClusteringOperation(0, 5, 4, 0.1, Merge.Sequence2Sequence)], {4}, ["A", "B"])     # a leaf without a label
