@@ -26,21 +26,22 @@ namespace {
 // One thread per frame.  Arithmetic order follows the reference: Mat::mul accumulates k ascending with a separate
 // multiply and add (numerics.rs:310-316; this unit is built with -ffp-contract=off), add_col, sigmoid, scale(255),
 // population mean / std over the latent values (numerics.rs:12-29), sigma floored at 1 (neural.rs:62), z-score.
-__global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ x, uint64_t t, uint32_t d_in,
-                                                     const float *__restrict__ w, const float *__restrict__ b,
-                                                     uint32_t latent, float *__restrict__ out)
-{
-    extern __shared__ float wb[];                               // w[d_in][latent] then b[latent]
-    for (uint32_t e = threadIdx.x; e < d_in * latent + latent; e += blockDim.x) wb[e] = e < d_in * latent ? w[e] : b[e - d_in * latent];
-    __syncthreads();
-    const float *bs = wb + d_in * latent;
-    for (uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; f < t; f += (uint64_t)gridDim.x * blockDim.x) {
-        const float *xf = x + f * d_in;
-        float *pred = out + f * latent;
+//
+// The kernel is a stream (cfg 4: 218 MB in, 134 MB out, ~300 flops per frame), so what matters is how the bytes move: a
+// wavefront takes 64 consecutive frames = one contiguous run of 64 * d_in floats, brings it into LDS with 16-byte coalesced
+// loads, lets every lane read ITS frame from LDS (row stride padded to an odd number of floats: conflict-free), computes, and
+// sends the 64 * latent results back through LDS as one contiguous run of 16-byte stores.  (The first version read frame
+// rows straight from global memory, 52 bytes apart per lane: 13 load instructions touching 52 cache lines each, 4.8 % of
+// the HBM rate.)
+struct EncodeFrame {
+    template <typename GetX, typename PutZ>
+    __device__ static __forceinline__ void run(uint32_t d_in, uint32_t latent, const float *__restrict__ wb, GetX x, PutZ put, float *__restrict__ pred)
+    {
+        const float *bs = wb + d_in * latent;
         float mean = 0.0f;
         for (uint32_t j = 0; j < latent; ++j) {
             float acc = 0.0f;
-            for (uint32_t k = 0; k < d_in; ++k) acc = acc + xf[k] * wb[k * latent + j];
+            for (uint32_t k = 0; k < d_in; ++k) acc = acc + x(k) * wb[k * latent + j];
             acc = acc + bs[j];
             const float s = 1.0f / (1.0f + expf(-acc));        // numerics.rs:233
             const float v = s * 255.0f;
@@ -51,87 +52,174 @@ __global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ x
         float sd = 0.0f;
         for (uint32_t j = 0; j < latent; ++j) { const float dv = pred[j] - mu; sd = sd + dv * dv; }
         const float sigma = fmaxf(sqrtf(sd / (float)latent), 1.0f);
-        for (uint32_t j = 0; j < latent; ++j) pred[j] = (pred[j] - mu) / sigma;
+        for (uint32_t j = 0; j < latent; ++j) put(j, (pred[j] - mu) / sigma);
+    }
+};
+
+__global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ x, uint64_t t, uint32_t d_in,
+                                                     const float *__restrict__ w, const float *__restrict__ b,
+                                                     uint32_t latent, float *__restrict__ out)
+{
+    extern __shared__ float wb[];                               // w[d_in][latent] then b[latent]
+    for (uint32_t e = threadIdx.x; e < d_in * latent + latent; e += blockDim.x) wb[e] = e < d_in * latent ? w[e] : b[e - d_in * latent];
+    __syncthreads();
+    for (uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; f < t; f += (uint64_t)gridDim.x * blockDim.x) {
+        const float *xf = x + f * d_in;
+        float *pred = out + f * latent;                         // the un-normalised values are parked in the output row
+        EncodeFrame::run(d_in, latent, wb, [&](uint32_t k) { return xf[k]; }, [&](uint32_t j, float v) { pred[j] = v; }, pred);
+    }
+}
+
+// The staged form.  LDS: [w | b] then, per wavefront, 64 input rows of stride_in floats and 64 output rows of stride_out.
+__global__ __launch_bounds__(256) void encode_staged_kernel(const float *__restrict__ x, uint64_t t, uint32_t d_in,
+                                                            const float *__restrict__ w, const float *__restrict__ b,
+                                                            uint32_t latent, float *__restrict__ out)
+{
+    extern __shared__ float lds[];
+    const uint32_t n_wb = d_in * latent + latent, stride_in = d_in | 1u, stride_out = latent | 1u;
+    float *wb = lds;
+    for (uint32_t e = threadIdx.x; e < n_wb; e += blockDim.x) wb[e] = e < d_in * latent ? w[e] : b[e - d_in * latent];
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *xin = lds + ((n_wb + 3u) & ~3u) + wave * 64u * (stride_in + stride_out), *zout = xin + 64u * stride_in;
+    const uint64_t n_chunks = (t + 63) / 64, waves = (uint64_t)gridDim.x * 4u;
+    for (uint64_t chunk = (uint64_t)blockIdx.x * 4u + wave; chunk < n_chunks; chunk += waves) {
+        const uint64_t f0 = chunk * 64;
+        const uint32_t frames = (uint32_t)min<uint64_t>(64, t - f0), n_in = frames * d_in, n_out = frames * latent;
+        const float *src = x + f0 * d_in;                       // 64 * d_in * 4 bytes per chunk: a multiple of 16, and hipMalloc aligns the base
+        const bool vec_in = ((uintptr_t)src & 15u) == 0;
+        for (uint32_t e = lane * 4u; e < n_in; e += 256u) {     // coalesced: 1 KB per wave instruction
+            float v[4];
+            if (vec_in && e + 4u <= n_in) { const float4 q = *reinterpret_cast<const float4 *>(src + e); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+            else for (uint32_t i = 0; i < 4; ++i) v[i] = e + i < n_in ? src[e + i] : 0.0f;
+            uint32_t fr = e / d_in, k = e - fr * d_in;
+            for (uint32_t i = 0; i < 4 && e + i < n_in; ++i) { xin[fr * stride_in + k] = v[i]; if (++k == d_in) { k = 0; ++fr; } }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // one wavefront: LDS runs in order, only the compiler must not reorder
+        if (lane < frames) {
+            const float *mine = xin + lane * stride_in;
+            float *pred = zout + lane * stride_out;
+            EncodeFrame::run(d_in, latent, wb, [&](uint32_t k) { return mine[k]; }, [&](uint32_t j, float v) { pred[j] = v; }, pred);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float *dst = out + f0 * latent;
+        const bool vec_out = ((uintptr_t)dst & 15u) == 0;
+        for (uint32_t e = lane * 4u; e < n_out; e += 256u) {
+            float v[4];
+            uint32_t fr = e / latent, j = e - fr * latent;
+            for (uint32_t i = 0; i < 4; ++i) { v[i] = e + i < n_out ? zout[fr * stride_out + j] : 0.0f; if (++j == latent) { j = 0; ++fr; } }
+            if (vec_out && e + 4u <= n_out) *reinterpret_cast<float4 *>(dst + e) = make_float4(v[0], v[1], v[2], v[3]);
+            else for (uint32_t i = 0; i < 4 && e + i < n_out; ++i) dst[e + i] = v[i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the rows are reused by the next chunk
     }
 }
 
 // -------------------------------------------------------------------------------------- cepstrum
-// One wavefront per frame, four frames per workgroup.  Hamming window, radix-2 Stockham FFT of the N real samples in
-// LDS (N a power of two), magnitudes of the first N/2 bins, triangular filterbank with stride L/2, ln(. + 1e-6),
-// DCT-I as a K x K table product, drop 4, subtract the mean of what is left (spectrogram.rs:51-79).
+// One wavefront per frame, wavefronts loop over frames.  Hamming window, DFT of the N real samples, magnitudes of the
+// first N/2 bins, triangular filterbank with stride L/2, ln(. + 1e-6), DCT-I as a K x K table product, drop 4, subtract
+// the mean of what is left (spectrogram.rs:51-79).  The DFT is a radix-2 Stockham FFT in LDS when N is a power of two and
+// the defining sum X_k = sum_s x_s e^(-2 pi i k s / N) otherwise (rustfft plans any length, spectrogram.rs:44-48; the
+// reference's shipped window is 256).  The tables live in LDS, loaded once per workgroup; the four wavefronts of a
+// workgroup never exchange data, so the stages are ordered by the wavefront's own in-order LDS queue, not by barriers.
 struct CepsParams {
     const int16_t *samples;
     const uint64_t *sample_off;   // [n_seq+1] first sample of every recording
     const uint64_t *frame_off;    // [n_seq+1] first output frame of every recording
     uint32_t n_seq;
     uint64_t n_frames;
-    uint64_t first_frame;      // frames first_frame .. of this launch (launches stay below 2^31 work-items)
-    uint32_t fft, step, L, fstep, K, log2n;
+    uint32_t fft, step, L, fstep, K, log2n;   // log2n == 0: N is not a power of two, direct DFT
     const float *hamming;      // [fft]
     const float *triag;        // [L]
-    const float2 *twiddle;     // [fft/2]  exp(-2 pi i k / fft)
+    const float2 *twiddle;     // power of two: [fft/2] exp(-2 pi i k / fft); else [fft] exp(-2 pi i t / fft)
     const float *dct;          // [K][K]   DCT-I table incl. the 1/2 weights of the end points
     float *out;                // [n_frames][K-4]
 };
+
+#define APD_WAVE_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 __global__ __launch_bounds__(256) void cepstrum_kernel(const CepsParams P)
 {
     extern __shared__ float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t N = P.fft, half = N / 2;
-    // per wave: two complex buffers of N (ping-pong), then mag[half], conv[K], ceps[K]
-    float *base = lds + (size_t)wave * (4 * N + half + 2 * P.K);
+    const uint32_t N = P.fft, half = N / 2, K = P.K, n_tw = P.log2n ? half : N;
+    // tables, shared by the workgroup
+    float *t_ham = lds, *t_tri = t_ham + N, *t_dct = t_tri + P.L;
+    float2 *t_tw = reinterpret_cast<float2 *>(lds + ((N + P.L + K * K + 1u) & ~1u));        // 8-byte aligned
+    for (uint32_t e = threadIdx.x; e < N; e += blockDim.x) t_ham[e] = P.hamming[e];
+    for (uint32_t e = threadIdx.x; e < P.L; e += blockDim.x) t_tri[e] = P.triag[e];
+    for (uint32_t e = threadIdx.x; e < K * K; e += blockDim.x) t_dct[e] = P.dct[e];
+    for (uint32_t e = threadIdx.x; e < n_tw; e += blockDim.x) t_tw[e] = P.twiddle[e];
+    __syncthreads();
+    // per wavefront: two complex buffers of N (ping-pong; the direct form uses the first as N real samples), mag[half], conv[K], ceps[K]
+    float *base = reinterpret_cast<float *>(t_tw + n_tw) + (size_t)wave * ((4 * N + half + 2 * K + 1u) & ~1u);
     float2 *bufa = reinterpret_cast<float2 *>(base), *bufb = bufa + N;
-    float *mag = base + 4 * N, *conv = mag + half, *ceps = conv + P.K;
-    const uint64_t frame = P.first_frame + (uint64_t)blockIdx.x * 4 + wave;
-    const bool live = frame < P.n_frames;
-    uint32_t lo = 0, hi = P.n_seq;                                // recording holding this frame: largest s with frame_off[s] <= frame
-    while (live && hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (P.frame_off[mid] <= frame) lo = mid; else hi = mid; }
-    const uint64_t start = live ? P.sample_off[lo] + (frame - P.frame_off[lo]) * P.step : 0;   // i - fft_size, i = fft + t * step (:51-53)
-    for (uint32_t s = lane; s < N; s += 64) {
-        const float v = live ? (float)P.samples[start + s] * P.hamming[s] : 0.0f;   // :55-59
-        bufa[s] = make_float2(v, 0.0f);
-    }
-    __syncthreads();
-    float2 *src = bufa, *dst = bufb;
-    for (uint32_t st = 0; st < P.log2n; ++st) {
-        const uint32_t Ns = 1u << st;
-        for (uint32_t j = lane; j < half; j += 64) {
-            const uint32_t k = j & (Ns - 1);
-            const float2 w = P.twiddle[k * (half / Ns)];           // exp(-2 pi i k / (2 Ns))
-            const float2 p = src[j], q0 = src[j + half];
-            const float2 q = make_float2(q0.x * w.x - q0.y * w.y, q0.x * w.y + q0.y * w.x);
-            const uint32_t idx = ((j - k) << 1) + k;
-            dst[idx] = make_float2(p.x + q.x, p.y + q.y);
-            dst[idx + Ns] = make_float2(p.x - q.x, p.y - q.y);
+    float *mag = base + 4 * N, *conv = mag + half, *ceps = conv + K;
+    const uint64_t n_waves = (uint64_t)gridDim.x * 4u;
+    for (uint64_t frame = (uint64_t)blockIdx.x * 4u + wave; frame < P.n_frames; frame += n_waves) {
+        uint32_t lo = 0, hi = P.n_seq;                             // recording holding this frame: largest s with frame_off[s] <= frame
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (P.frame_off[mid] <= frame) lo = mid; else hi = mid; }
+        const uint64_t start = P.sample_off[lo] + (frame - P.frame_off[lo]) * P.step;   // i - fft_size, i = fft + t * step (:51-53)
+        if (P.log2n) {
+            for (uint32_t s = lane; s < N; s += 64) bufa[s] = make_float2((float)P.samples[start + s] * t_ham[s], 0.0f);   // :55-59
+            APD_WAVE_LDS_FENCE();
+            float2 *src = bufa, *dst = bufb;
+            for (uint32_t st = 0; st < P.log2n; ++st) {
+                const uint32_t Ns = 1u << st;
+                for (uint32_t j = lane; j < half; j += 64) {
+                    const uint32_t k = j & (Ns - 1);
+                    const float2 w = t_tw[k * (half / Ns)];        // exp(-2 pi i k / (2 Ns))
+                    const float2 p = src[j], q0 = src[j + half];
+                    const float2 q = make_float2(q0.x * w.x - q0.y * w.y, q0.x * w.y + q0.y * w.x);
+                    const uint32_t idx = ((j - k) << 1) + k;
+                    dst[idx] = make_float2(p.x + q.x, p.y + q.y);
+                    dst[idx + Ns] = make_float2(p.x - q.x, p.y - q.y);
+                }
+                APD_WAVE_LDS_FENCE();
+                float2 *tmp = src; src = dst; dst = tmp;
+            }
+            for (uint32_t k = lane; k < half; k += 64) {
+                const float2 v = src[k];
+                mag[k] = sqrtf(v.x * v.x + v.y * v.y);             // norm_sqr().sqrt() (:63)
+            }
+        } else {
+            float *win = base;                                     // N windowed samples
+            for (uint32_t s = lane; s < N; s += 64) win[s] = (float)P.samples[start + s] * t_ham[s];
+            APD_WAVE_LDS_FENCE();
+            for (uint32_t k = lane; k < half; k += 64) {           // X_k = sum_s x_s (cos - i sin)(2 pi k s / N)
+                float re = 0.0f, im = 0.0f;
+                uint32_t idx = 0;                                  // (k * s) mod N
+                for (uint32_t s = 0; s < N; ++s) {
+                    const float2 w = t_tw[idx];
+                    const float x = win[s];
+                    re = fmaf(x, w.x, re);
+                    im = fmaf(x, w.y, im);
+                    idx += k;
+                    if (idx >= N) idx -= N;
+                }
+                mag[k] = sqrtf(re * re + im * im);
+            }
         }
-        __syncthreads();
-        float2 *tmp = src; src = dst; dst = tmp;
+        APD_WAVE_LDS_FENCE();
+        for (uint32_t c = lane; c < K; c += 64) {                  // convolve (numerics.rs:102-109)
+            const uint32_t p = P.L + c * P.fstep;
+            float dot = 0.0f;
+            for (uint32_t q = 0; q < P.L; ++q) dot = dot + t_tri[q] * mag[p - P.L + q];
+            conv[c] = logf(dot + 1e-6f);                           // :69
+        }
+        APD_WAVE_LDS_FENCE();
+        for (uint32_t k = lane; k < K; k += 64) {                  // DCT-I (:71-73)
+            float acc = 0.0f;
+            for (uint32_t q = 0; q < K; ++q) acc = acc + t_dct[k * K + q] * conv[q];
+            ceps[k] = acc;
+        }
+        APD_WAVE_LDS_FENCE();
+        float mu = 0.0f;
+        for (uint32_t k = 4; k < K; ++k) mu = mu + ceps[k];        // mean of cepstrum[4..] (:74, numerics.rs:12-18)
+        mu = mu / (float)(K - 4);
+        for (uint32_t k = 4 + lane; k < K; k += 64) P.out[frame * (K - 4) + (k - 4)] = ceps[k] - mu;   // :75-79
+        APD_WAVE_LDS_FENCE();                                      // the buffers are reused by this wavefront's next frame
     }
-    for (uint32_t k = lane; k < half; k += 64) {
-        const float2 v = src[k];
-        const float nsq = v.x * v.x + v.y * v.y;                   // norm_sqr (:63)
-        mag[k] = sqrtf(nsq);
-    }
-    __syncthreads();
-    for (uint32_t c = lane; c < P.K; c += 64) {                    // convolve (numerics.rs:102-109)
-        const uint32_t p = P.L + c * P.fstep;
-        float dot = 0.0f;
-        for (uint32_t q = 0; q < P.L; ++q) dot = dot + P.triag[q] * mag[p - P.L + q];
-        conv[c] = logf(dot + 1e-6f);                               // :69
-    }
-    __syncthreads();
-    for (uint32_t k = lane; k < P.K; k += 64) {                    // DCT-I (:71-73)
-        float acc = 0.0f;
-        for (uint32_t q = 0; q < P.K; ++q) acc = acc + P.dct[k * P.K + q] * conv[q];
-        ceps[k] = acc;
-    }
-    __syncthreads();
-    float mu = 0.0f;
-    for (uint32_t k = 4; k < P.K; ++k) mu = mu + ceps[k];          // mean of cepstrum[4..] (:74, numerics.rs:12-18)
-    mu = mu / (float)(P.K - 4);
-    if (live)
-        for (uint32_t k = 4 + lane; k < P.K; k += 64) P.out[frame * (P.K - 4) + (k - 4)] = ceps[k] - mu;   // :75-79
 }
 
 // ------------------------------------------------------------------------------------------ VAT
@@ -228,8 +316,15 @@ extern "C" int apd_encode(apd_context *ctx, const float *x, uint64_t t, uint32_t
     }
     if (rc == APD_OK) {
         const unsigned blocks = (unsigned)std::min<uint64_t>((t + 255) / 256, 8192);
-        hipLaunchKernelGGL(encode_kernel, dim3(blocks), dim3(256), wb_bytes, ctx->stream, xin, t, d_in, d_w, d_w + (size_t)d_in * latent,
-                           latent, xout);
+        // staged through LDS when the 4 x 64 staged rows fit next to the weights (they do for every shape the reference produces)
+        const size_t staged_bytes = (((size_t)d_in * latent + latent + 3) & ~(size_t)3) * sizeof(float) +
+                                    4 * 64 * (size_t)((d_in | 1u) + (latent | 1u)) * sizeof(float);
+        if (staged_bytes <= 64 * 1024)
+            hipLaunchKernelGGL(encode_staged_kernel, dim3(blocks), dim3(256), staged_bytes, ctx->stream, xin, t, d_in, d_w,
+                               d_w + (size_t)d_in * latent, latent, xout);
+        else
+            hipLaunchKernelGGL(encode_kernel, dim3(blocks), dim3(256), wb_bytes, ctx->stream, xin, t, d_in, d_w, d_w + (size_t)d_in * latent,
+                               latent, xout);
         guard(hipGetLastError());
     }
     if (!on_device && rc == APD_OK) guard(hipMemcpyAsync(out, d_out, t * latent * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -262,13 +357,16 @@ static int cepstrum_impl(apd_context *ctx, const int16_t *samples, const uint64_
     if (!samples) return APD_ERR_INVALID_ARG;
     uint32_t log2n = 0;
     while ((1u << log2n) < fft_size) ++log2n;
-    if ((1u << log2n) != fft_size || fft_size < 4 || fft_size > 2048 || K > 512) return APD_ERR_UNSUPPORTED;   // power-of-two windows only
+    if ((1u << log2n) != fft_size) log2n = 0;                                           // not a power of two: the defining sum
+    if (fft_size < 4 || fft_size > 4096 || K > 512) return APD_ERR_UNSUPPORTED;
+    const uint32_t n_tw = log2n ? half : fft_size;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     // tables, computed as the reference computes them
-    std::vector<float> tab(fft_size + L + (size_t)K * K + fft_size);
+    const size_t tw_off = ((size_t)fft_size + L + (size_t)K * K + 1) & ~(size_t)1;      // float2 table: 8-byte aligned
+    std::vector<float> tab(tw_off + 2 * (size_t)n_tw);
     float *hamming = tab.data(), *triag = hamming + fft_size, *dct = triag + L;
-    float2 *tw = reinterpret_cast<float2 *>(dct + (size_t)K * K);
+    float2 *tw = reinterpret_cast<float2 *>(tab.data() + tw_off);
     for (uint32_t i = 0; i < fft_size; ++i) {                                           // numerics.rs:60-66
         const float arg = (2.0f * 3.14159265358979323846f * (float)i) / (float)fft_size;
         hamming[i] = 0.54f + 0.46f * cosf(arg);
@@ -283,7 +381,7 @@ static int cepstrum_impl(apd_context *ctx, const int16_t *samples, const uint64_
             else c = std::cos(M_PI * (double)q * (double)k / (double)(K - 1));
             dct[(size_t)k * K + q] = (float)c;
         }
-    for (uint32_t k = 0; k < half; ++k) {
+    for (uint32_t k = 0; k < n_tw; ++k) {
         const double a = -2.0 * M_PI * (double)k / (double)fft_size;
         tw[k] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
@@ -306,20 +404,18 @@ static int cepstrum_impl(apd_context *ctx, const int16_t *samples, const uint64_
     P.n_seq = n_seq; P.n_frames = T; P.fft = fft_size; P.step = fft_step; P.L = L; P.fstep = fstep; P.K = K; P.log2n = log2n;
     const float *d_tab = reinterpret_cast<const float *>(pool);
     P.hamming = d_tab; P.triag = d_tab + fft_size; P.dct = d_tab + fft_size + L;
-    P.twiddle = reinterpret_cast<const float2 *>(d_tab + fft_size + L + (size_t)K * K);
+    P.twiddle = reinterpret_cast<const float2 *>(d_tab + tw_off);
     P.out = on_device ? out : reinterpret_cast<float *>(pool + out_off);
-    const size_t lds_bytes = 4 * (4 * (size_t)fft_size + half + 2 * K) * sizeof(float);
+    const size_t table_floats = tw_off + 2 * (size_t)n_tw;                               // the kernel lays its LDS out the same way
+    const size_t lds_bytes = (table_floats + 4 * ((4 * (size_t)fft_size + half + 2 * K + 1) & ~(size_t)1)) * sizeof(float);
     if (lds_bytes > 160 * 1024) rc = APD_ERR_UNSUPPORTED;
     if (rc == APD_OK && lds_bytes > 64 * 1024)
         guard(hipFuncSetAttribute(reinterpret_cast<const void *>(cepstrum_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     if (rc == APD_OK) {
-        constexpr uint64_t kFramesPerLaunch = 1ull << 24;                 // 2^22 workgroups of 256
-        for (uint64_t f0 = 0; f0 < T && rc == APD_OK; f0 += kFramesPerLaunch) {
-            P.first_frame = f0;
-            const uint64_t cnt = std::min(kFramesPerLaunch, T - f0);
-            hipLaunchKernelGGL(cepstrum_kernel, dim3((unsigned)((cnt + 3) / 4)), dim3(256), lds_bytes, ctx->stream, P);
-            guard(hipGetLastError());
-        }
+        // wavefronts loop over frames: enough workgroups to fill the GPU several times over, tables loaded once per workgroup
+        const unsigned blocks = (unsigned)std::min<uint64_t>((T + 3) / 4, 256 * 16);
+        hipLaunchKernelGGL(cepstrum_kernel, dim3(blocks), dim3(256), lds_bytes, ctx->stream, P);
+        guard(hipGetLastError());
     }
     if (!on_device && rc == APD_OK) guard(hipMemcpyAsync(out, pool + out_off, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     guard(hipStreamSynchronize(ctx->stream));

@@ -72,7 +72,8 @@ def test_cepstrum_golden_and_shapes(ctx, oracle):
     assert NDSequence.new(256, 128, 18, g["audio"][:385], ctx).len() == 2
 
 
-@pytest.mark.parametrize("fft,step,filt", [(256, 128, 18), (256, 64, 32), (512, 256, 32), (128, 32, 8), (1024, 512, 64)])
+@pytest.mark.parametrize("fft,step,filt", [(256, 128, 18), (256, 64, 32), (512, 256, 32), (128, 32, 8), (1024, 512, 64),
+                                           (300, 128, 18), (250, 100, 20), (441, 220, 21), (1000, 500, 50), (96, 33, 12)])
 def test_cepstrum_random_audio(ctx, oracle, fft, step, filt):
     from audio_pattern_discovery_amd.alignments import NDSequence
     audio = synth.make_audio(fft + step * 37 + 3, seed=fft + filt)
@@ -83,11 +84,44 @@ def test_cepstrum_random_audio(ctx, oracle, fft, step, filt):
     assert np.abs(got.frames.mean(axis=1)).max() < 1e-4            # mean-centred bins (spectrogram.rs:74-75)
 
 
-def test_cepstrum_unsupported_window(ctx, apd):
+def test_cepstrum_window_limits(ctx, apd):
+    """Any window length up to 4096 (rustfft plans any length, spectrogram.rs:44-48): powers of two by FFT, the others by the
+    defining sum.  Beyond the limit, and filter banks that leave fewer than 5 outputs, are refused."""
     from audio_pattern_discovery_amd.alignments import NDSequence
+    assert NDSequence.new(300, 128, 18, synth.make_audio(2000, seed=1), ctx).n_bins > 0
     with pytest.raises(apd.ApdError) as e:
-        NDSequence.new(300, 128, 18, synth.make_audio(2000, seed=1), ctx)     # not a power of two
+        NDSequence.new(8192, 128, 18, synth.make_audio(20000, seed=1), ctx)
     assert e.value.status == apd.APD_ERR_UNSUPPORTED
+    with pytest.raises(apd.ApdError) as e:
+        NDSequence.new(256, 128, 2, synth.make_audio(2000, seed=1), ctx)        # L = 128: no filter output
+    assert e.value.status == apd.APD_ERR_INVALID_ARG
+
+
+def test_encoder_shapes_and_alignment(ctx, oracle, apd):
+    """The staged encoder (64 frames per wavefront through LDS): frame counts around the chunk size, even and odd dimensions
+    (row padding), an output that does not start on a 16-byte boundary, and the un-staged fallback for wide frames."""
+    import ctypes as C
+    import torch
+    from audio_pattern_discovery_amd.neural import AutoEncoder
+    rng = np.random.default_rng(11)
+    for d_in, latent, t in [(13, 8, 63), (13, 8, 64), (13, 8, 65), (26, 10, 1000), (12, 7, 129), (16, 16, 257), (3, 2, 1), (200, 40, 300)]:
+        x = (rng.standard_normal((t, d_in)) * 2).astype(np.float32)
+        w = ((rng.random((d_in, latent)) - 0.5) / latent).astype(np.float32)
+        b = ((rng.random(latent) - 0.5) / latent).astype(np.float32)
+        np.testing.assert_allclose(AutoEncoder(w, b).predict_frames(x, ctx), oracle.encode(x, w, b), rtol=1e-5, atol=1e-5)
+    # device pointers one float off a 16-byte boundary
+    d_in, latent, t = 13, 8, 500
+    x = (rng.standard_normal((t, d_in)) * 2).astype(np.float32)
+    w = ((rng.random((d_in, latent)) - 0.5) / latent).astype(np.float32)
+    b = ((rng.random(latent) - 0.5) / latent).astype(np.float32)
+    d_x = torch.zeros(t * d_in + 1, dtype=torch.float32, device="cuda")
+    d_x[1:] = torch.from_numpy(x.ravel()).cuda()
+    d_z = torch.zeros(t * latent + 3, dtype=torch.float32, device="cuda")
+    f32p = C.POINTER(C.c_float)
+    apd.check(apd.lib().apd_encode(ctx.handle, C.c_void_p(d_x.data_ptr() + 4), t, d_in, w.ctypes.data_as(f32p), b.ctypes.data_as(f32p), latent, 1,
+                                   C.c_void_p(d_z.data_ptr() + 12)), ctx.handle)
+    ctx.synchronize()
+    np.testing.assert_allclose(d_z.cpu().numpy()[3:].reshape(t, latent), oracle.encode(x, w, b), rtol=1e-5, atol=1e-5)
 
 
 def test_audio_to_clusters_on_device(ctx, oracle, apd):
