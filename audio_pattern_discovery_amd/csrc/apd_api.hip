@@ -281,7 +281,7 @@ extern "C" int apd_batch_create(apd_context *ctx, const float *frames, const uin
     b->offsets.assign(n_seq + 1, 0);                                     // offsets of the RESIDENT order
     // device metadata, one allocation and one copy: [seq_off | src_off | order | flags]
     const size_t m1 = (size_t)n_seq + 1;
-    b->h_meta.assign(3 * m1 + 4, 0u);
+    b->h_meta.assign(4 * m1 + 4, 0u);
     uint32_t *off32 = b->h_meta.data(), *src32 = off32 + m1, *ord32 = src32 + m1;
     for (uint32_t p = 0; p < n_seq; ++p) {
         b->offsets[p + 1] = b->offsets[p] + (offsets[b->order[p] + 1] - offsets[b->order[p]]);
@@ -296,6 +296,7 @@ extern "C" int apd_batch_create(apd_context *ctx, const float *frames, const uin
     if (hipMalloc((void **)&b->d_frames, padded_bytes) != hipSuccess) return fail(APD_ERR_OOM);
     if (hipMalloc((void **)&b->d_meta, b->h_meta.size() * sizeof(uint32_t)) != hipSuccess) return fail(APD_ERR_OOM);
     b->d_seq_off = b->d_meta; b->d_src_off = b->d_meta + m1; b->d_order = b->d_meta + 2 * m1; b->d_flags = b->d_meta + 3 * m1;
+    b->d_seq_nmax = reinterpret_cast<float *>(b->d_meta + 3 * m1 + 4);
     if (hipMemcpyAsync(b->d_meta, b->h_meta.data(), b->h_meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         return fail(APD_ERR_HIP);                                         // h_meta lives as long as the batch: no sync needed
     ctx->batches.insert(b);
@@ -312,7 +313,7 @@ extern "C" int apd_batch_refill(apd_context *ctx, apd_batch *b, const float *fra
     if (total > 0 && !frames) return APD_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     b->nonfinite = -1;
-    HIP_TRY(ctx, hipMemsetAsync(b->d_flags, 0, 4 * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(b->d_flags, 0, (4 + (size_t)b->n_seq + 1) * sizeof(uint32_t), ctx->stream));   // flags and the per-sequence norm maxima
     if (padded_frames > 0) {
         const float *d_src = frames;
         float *d_tmp = nullptr;
@@ -325,7 +326,7 @@ extern "C" int apd_batch_refill(apd_context *ctx, apd_batch *b, const float *fra
             }
             d_src = d_tmp;
         }
-        hipError_t e = launch_pad(d_src, b->d_frames, b->d_seq_off, b->d_src_off, b->n_seq, padded_frames, dim, b->dim, b->dpad, b->d_flags, ctx->stream);
+        hipError_t e = launch_pad(d_src, b->d_frames, b->d_seq_off, b->d_src_off, b->n_seq, padded_frames, dim, b->dim, b->dpad, b->d_flags, b->d_seq_nmax, ctx->stream);
         if (d_tmp) { hipStreamSynchronize(ctx->stream); hipFree(d_tmp); }
         if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return APD_ERR_HIP; }
     }
@@ -361,7 +362,7 @@ static void release_batch_device_memory(apd_batch *b)
     b->tile_cache.clear();
     if (b->d_frames) hipFree(b->d_frames);
     if (b->d_meta) hipFree(b->d_meta);
-    b->d_frames = nullptr; b->d_meta = nullptr; b->d_seq_off = nullptr; b->d_src_off = nullptr; b->d_order = nullptr; b->d_flags = nullptr;
+    b->d_frames = nullptr; b->d_meta = nullptr; b->d_seq_off = nullptr; b->d_src_off = nullptr; b->d_order = nullptr; b->d_flags = nullptr; b->d_seq_nmax = nullptr;
 }
 
 extern "C" int apd_batch_destroy(apd_batch *b)
@@ -598,7 +599,7 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
     // skipped class) reaches the matrix as NaN and raises APD_ERR_INCOMPLETE in the unpack -- never a stale or zero distance.
     HIP_TRY(ctx, hipMemsetAsync(d_slab, 0xFF, apd_slab_floats(batch->n_seq, world) * sizeof(float), ctx->stream));
     AlignLaunch L{};
-    L.d_frames = batch->d_frames; L.frames_bytes = batch->frames_bytes; L.d_seq_off = batch->d_seq_off;
+    L.d_frames = batch->d_frames; L.frames_bytes = batch->frames_bytes; L.d_seq_off = batch->d_seq_off; L.d_seq_nmax = batch->d_seq_nmax;
     L.n_seq = batch->n_seq; L.dim = batch->dim; L.dpad = batch->dpad; L.band = band; L.d_slab = d_slab;
     L.variant = ctx->variant;
     L.hybrid = ctx->distance_mode; L.tau = ctx->tau;

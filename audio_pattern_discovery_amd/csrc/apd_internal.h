@@ -31,6 +31,7 @@ struct AlignLaunch {
     const float *d_frames;       // resident layout, see dtw_generic.hip: [frames | sentinel H | sentinel E] per sequence, dpad floats per frame
     uint32_t frames_bytes;       // size of d_frames in bytes (0 if >= 4 GiB: buffer addressing unavailable)
     const uint32_t *d_seq_off;   // [n_seq+1] padded frame offsets (sequence s owns seq_off[s+1]-seq_off[s]-2 real frames)
+    const float *d_seq_nmax;     // [n_seq] largest squared frame norm of every resident sequence (bound of the hybrid form's threshold test)
     const uint4 *d_tiles;        // [n_tiles] (tile_a, tile_b, index of the tile in the slab, unused), tile_a <= tile_b
     uint32_t n_tiles;
     uint32_t n_seq;
@@ -63,8 +64,10 @@ double full_key_cost(uint32_t cols, uint32_t rows, uint32_t dim, int key);    //
 // >= 30000: the same column strips with a binding band (two DPs): 30000 + (pairs per wavefront) * 100 + CW
 int pick_banded_strip_key(uint32_t cols, uint32_t rows, uint32_t dim, int variant);
 // d_flags[0] is raised when a frame holds a NaN or an infinity (the fast kernels' selects and sentinels assume finite features)
+// d_seq_nmax[p] (zeroed by the caller) receives the largest squared frame norm of resident sequence p
 hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_off, const uint32_t *d_src_off, uint32_t n_seq,
-                      uint64_t n_frames_padded, uint32_t src_dim, uint32_t dim, uint32_t dpad, uint32_t *d_flags, hipStream_t stream);
+                      uint64_t n_frames_padded, uint32_t src_dim, uint32_t dim, uint32_t dpad, uint32_t *d_flags, float *d_seq_nmax,
+                      hipStream_t stream);
 // writes EVERY entry of d_out (diagonal included); *d_status |= 1 when a pair score of a batch with finite frames is NaN,
 // i.e. still carries the poison its slab was filled with before the alignment launches
 hipError_t launch_unpack(const float *d_gathered, float *d_out, const uint32_t *d_order, uint32_t n_seq, uint32_t world,
@@ -128,12 +131,13 @@ struct apd_batch {
     uint64_t total_frames = 0;
     float *d_frames = nullptr;        // padded layout with sentinels (see dtw_generic.hip)
     uint32_t frames_bytes = 0;
-    uint32_t *d_meta = nullptr;       // ONE allocation: [seq_off n+1 | src_off n+1 | order n+1 | flags 4], filled by one copy of h_meta
+    uint32_t *d_meta = nullptr;       // ONE allocation: [seq_off n+1 | src_off n+1 | order n+1 | flags 4 | nmax n+1], filled by one copy of h_meta
     std::vector<uint32_t> h_meta;     // host image of d_meta, alive as long as the batch (the H2D copy is asynchronous)
     uint32_t *d_seq_off = nullptr;
     uint32_t *d_src_off = nullptr;    // first frame of resident sequence p in the caller's frame array
     uint32_t *d_order = nullptr;      // resident position p -> caller's sequence index
     uint32_t *d_flags = nullptr;      // [0] 1: some frame holds a NaN / infinity (raised by the repack kernel)
+    float *d_seq_nmax = nullptr;      // [n_seq] largest squared frame norm per resident sequence (written by the repack kernel)
     mutable int nonfinite = -1;       // host copy of d_flags[0]; -1: not read back yet
     std::vector<uint32_t> order;      // host copy of d_order
     std::vector<uint64_t> offsets;    // frame offsets of the RESIDENT order (host)

@@ -87,6 +87,9 @@ __device__ __forceinline__ float select_node(float del_v, float ins_v, float m_v
         // m_v.  So base = (del_v == ins_v) ? m_v : min3(del_v, ins_v, m_v): 3 VALU ops, no scalar mask arithmetic.
         // (Identical to the branch chain for non-NaN inputs; NaN features are outside the supported domain.)
         const float lo = __builtin_fminf(__builtin_fminf(del_v, ins_v), m_v);
+#if defined(APD_ABLATE) && (APD_ABLATE & 64)
+        return lo + d;                                            // timing only: no tie rule, no band guards (results wrong)
+#endif
         return (((del_v == ins_v) | force_match) ? m_v : lo) + d;
     }
     const bool pick_d = (del_v < m_v) & (del_v < ins_v) & !force_match;
@@ -115,6 +118,7 @@ struct PairInfo {
     int n, m, w;
     int slot_a, slot_b;
     uint32_t slab_tile;     // position of the tile in the rank's slab
+    float nmax_b;           // largest squared frame norm of sequence b
     bool valid;
 };
 
@@ -125,6 +129,7 @@ __device__ __forceinline__ PairInfo decode_pair(const AlignLaunch &L, uint32_t t
     p.slot_b = slot % kTile;
     p.valid = false;
     p.slab_tile = 0;
+    p.nmax_b = 0.0f;
     p.A = p.B = L.d_frames; p.n = p.m = 2; p.w = 2;
     if (tile >= L.n_tiles) return p;
     const uint4 t = L.d_tiles[tile];
@@ -138,6 +143,7 @@ __device__ __forceinline__ PairInfo decode_pair(const AlignLaunch &L, uint32_t t
     p.A = L.d_frames + (uint64_t)oa * L.dpad;
     p.B = L.d_frames + (uint64_t)ob * L.dpad;
     p.w = pair_w(L.band, p.n, p.m);
+    p.nmax_b = L.d_seq_nmax[b];
     return p;
 }
 

@@ -25,6 +25,7 @@
 // holds (C chosen at run time, per-lane DP rows in LDS, every boundary tested per cell, any penalty values).
 // dtw_systolic.h holds the production kernel.
 #include <cmath>
+#include <cstdlib>
 #include "dtw_common.h"
 
 namespace apd {
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(64) void dtw_fused_generic(const AlignLaunch L, int
 // ------------------------------------------------------------------------------------------------
 __global__ void pad_frames_kernel(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ seq_off,
                                   const uint32_t *__restrict__ src_off, uint32_t n_seq, uint64_t n_frames_padded, uint32_t src_dim,
-                                  uint32_t dim, uint32_t dpad, uint32_t *__restrict__ flags)
+                                  uint32_t dim, uint32_t dpad, uint32_t *__restrict__ flags, float *__restrict__ seq_nmax)
 {
     const uint64_t total = n_frames_padded * dpad;
     bool nonfinite = false;
@@ -127,7 +128,13 @@ __global__ void pad_frames_kernel(const float *__restrict__ src, float *__restri
         else {
             const float *fr = src + (uint64_t)(src_off[lo] + (f - seq_off[lo])) * src_dim;
             if (k < src_dim) { v = fr[k]; nonfinite |= !(__builtin_fabsf(v) < APD_INF); }   // NaN or +-INF; components src_dim .. dim - 1 stay zero
-            else if (k == dim) { double acc = 0.0; for (uint32_t t = 0; t < src_dim; ++t) acc += (double)fr[t] * (double)fr[t]; v = (float)acc; }
+            else if (k == dim) {
+                double acc = 0.0;
+                for (uint32_t t = 0; t < src_dim; ++t) acc += (double)fr[t] * (double)fr[t];
+                v = (float)acc;
+                // largest norm of the sequence: non-negative floats order like their bit patterns (a NaN norm flags the batch anyway)
+                if (v == v) atomicMax(reinterpret_cast<unsigned int *>(&seq_nmax[lo]), __builtin_bit_cast(unsigned int, v));
+            }
         }
         dst[e] = v;
     }
@@ -189,13 +196,14 @@ hipError_t launch_selftest(int *d_result, hipStream_t stream)
 }
 
 hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_off, const uint32_t *d_src_off, uint32_t n_seq,
-                      uint64_t n_frames_padded, uint32_t src_dim, uint32_t dim, uint32_t dpad, uint32_t *d_flags, hipStream_t stream)
+                      uint64_t n_frames_padded, uint32_t src_dim, uint32_t dim, uint32_t dpad, uint32_t *d_flags, float *d_seq_nmax,
+                      hipStream_t stream)
 {
     if (n_frames_padded == 0) return hipSuccess;
     const uint64_t total = n_frames_padded * dpad;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 16384);
     hipLaunchKernelGGL(pad_frames_kernel, dim3(blocks), dim3(256), 0, stream, d_src, d_dst, d_seq_off, d_src_off, n_seq, n_frames_padded,
-                       src_dim, dim, dpad, d_flags);
+                       src_dim, dim, dpad, d_flags, d_seq_nmax);
     return hipGetLastError();
 }
 
@@ -332,7 +340,8 @@ static hipError_t launch_align_chunk(const AlignLaunch &L, int geom_key, hipStre
     const bool unit = (b.ins == 1.0f) && (b.del == 1.0f) && (b.mat == 1.0f);   // the systolic kernel's UNIFORM_PEN path: no weighting at all
     bool done = false;
     AlignLaunch LL = L;
-    if (LL.dim < 10) LL.hybrid = 0;            // the norm expansion saves D - 4 vector ops per cell: not worth its branch below D = 10
+    static const int hybrid_min_dim = std::getenv("APD_HYBRID_MIN_DIM") ? std::atoi(std::getenv("APD_HYBRID_MIN_DIM")) : 10;   // tuning aid
+    if ((int)LL.dim < hybrid_min_dim) LL.hybrid = 0;   // the norm expansion saves D - 4 vector ops per cell: not worth its branch below D = 10
     if (geom_key >= 20000) {
         const bool banded = geom_key >= 30000;
         const int nw = (geom_key % 10000) / 100, cw = geom_key % 100;

@@ -19,6 +19,7 @@
 
 // Timing-only ablations for kernel tuning (results become wrong): build one unit with -DAPD_ABLATE=<bits>.
 //   1 no sqrt   2 no DP rows   4 no frame shifts   8 no edge fetches   16 no band guards   32 software-pipelined distances (valid results)
+//   64 select = min3 + d (no tie rule, no guards: what a deferred tie check could save at most)   128 no hybrid threshold test
 #ifndef APD_ABLATE
 #define APD_ABLATE 0
 #endif
@@ -138,8 +139,8 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     const uint32_t a_off = (uint32_t)(P.A - L.d_frames) * 4u, b_off = (uint32_t)(P.B - L.d_frames) * 4u;   // bytes
     constexpr uint32_t FB = DP * 4u;                             // bytes per padded frame
     float ins = L.band.ins, del = L.band.del, mat = L.band.mat;
-    float tau_thr = L.tau;
-    asm volatile("" : "+v"(ins), "+v"(del), "+v"(mat), "+v"(tau_thr));   // keep them in VGPRs: an SGPR operand doubles a VOP2's issue cost
+    float tau_thr = L.tau, nmax_b = P.nmax_b;
+    asm volatile("" : "+v"(ins), "+v"(del), "+v"(mat), "+v"(tau_thr), "+v"(nmax_b));   // keep them in VGPRs: an SGPR operand doubles a VOP2's issue cost
     // row-frame ring of this wave: slot = row & (R - 1); rows <= 0 hold -INF.  R > 2U + G - 2 keeps a refill from
     // overwriting a row some lane still needs.
     constexpr int R = (G == 64) ? 128 : 64;                      // G = 32, U <= 10: 2U + G - 2 = 50 < 64
@@ -276,13 +277,19 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                 if (HYBRID) {
                     // |x|^2 + |y|^2 - 2 x.y; where that is below tau (|x|^2 + |y|^2) cancellation has eaten the digits:
                     // such cells are recomputed in the difference form (wave-uniform branch, rare for unrelated frames)
-                    bool any = false;
+                    // One test per macro-step instead of one per cell: if some cell has d2_c < tau (|x|^2 + |y_c|^2) then the
+                    // smallest d2 of the lane is below tau (|x|^2 + N_b), N_b the largest frame norm of sequence b -- a superset
+                    // of the per-cell condition (never misses a cell; on a hit the exact per-cell test below decides).
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
                         float sc;
                         d[c] = frame_sq_expanded<D>(xs[xa], yf[(r + c) % S], sc);
-                        any |= d[c] < sc * tau_thr;
                     }
+                    float dmin = d[0];
+#pragma unroll
+                    for (int c = 1; c + 1 < C; c += 2) dmin = __builtin_fminf(__builtin_fminf(dmin, d[c]), d[c + 1]);
+                    if (C % 2 == 0) dmin = __builtin_fminf(dmin, d[C - 1]);
+                    const bool any = (APD_ABLATE & 128) ? false : dmin < (xs[xa][D] + nmax_b) * tau_thr;
                     if (__ballot(any) != 0ull) {
 #pragma unroll
                         for (int c = 0; c < C; ++c) {
