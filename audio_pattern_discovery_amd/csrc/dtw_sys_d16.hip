@@ -1,8 +1,6 @@
-// Instantiates the systolic, wide and full-matrix fused-pair DTW kernels for frame dimension 16 (one unit per D: parallel builds).
-#include "dtw_wide.h"
-#include "dtw_full.h"
+// Instantiates the systolic fused-pair DTW kernels for frame dimension 16 (one unit per D and kernel family: parallel builds,
+// per-family compiler flags -- see the Makefile).
+#include "dtw_systolic.h"
 namespace apd {
 template bool launch_systolic<16>(const AlignLaunch &, int, int, bool, hipStream_t);
-template bool launch_wide<16>(const AlignLaunch &, int, int, hipStream_t, hipError_t *);
-template bool launch_full<16>(const AlignLaunch &, bool, int, int, hipStream_t, hipError_t *);
 }

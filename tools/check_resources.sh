@@ -1,13 +1,13 @@
 #!/bin/bash
-# Lists VGPR / scratch / occupancy of every alignment kernel instantiation; exits 1 if a systolic kernel uses scratch.
+# Lists VGPR / scratch / occupancy of every alignment kernel instantiation; exits 1 if one of them uses scratch.
 cd "$(dirname "$0")/../audio_pattern_discovery_amd/csrc"
-bad=0
-for d in 8 10 13 16 20 26; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize --cuda-device-only -Rpass-analysis=kernel-resource-usage -c dtw_sys_d$d.hip -o /dev/null 2>&1 \
+for fam in sys wf; do for d in 8 10 13 16 20 26; do
+  extra=""; [ "$fam$d" = "sys13" ] && extra="-mllvm -amdgpu-sched-strategy=iterative-ilp"       # as the Makefile builds it
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize $extra --cuda-device-only -Rpass-analysis=kernel-resource-usage -c dtw_${fam}_d$d.hip -o /dev/null 2>&1 \
    | grep -E "Function Name|VGPRs:|ScratchSize|Occupancy" | sed -E 's/.*remark: +//; s/ \[-Rpass.*//' | paste - - - - \
-   | sed -E 's/Function Name: _ZN3apd18dtw_fused_systolicILi([0-9]+)ELi([0-9]+)ELi([0-9]+)ELb([01])ELb([01])EEEvNS_11AlignLaunchE/D=\1 C=\2 G=\3 uniform=\4 hybrid=\5/' > /tmp/apd_res_$d.txt &
-done
+   | sed -E 's/Function Name: _ZN3apd18dtw_fused_systolicILi([0-9]+)ELi([0-9]+)ELi([0-9]+)ELb([01])ELb([01])EEEvNS_11AlignLaunchE/systolic D=\1 C=\2 G=\3 uniform=\4 hybrid=\5/' > /tmp/apd_res_${fam}_$d.txt &
+done; done
 wait
-cat /tmp/apd_res_*.txt
-if grep -v "ScratchSize \[bytes/lane\]: 0" /tmp/apd_res_*.txt | grep -q Scratch; then echo "SCRATCH IN USE"; exit 1; fi
+cat /tmp/apd_res_*_*.txt
+if grep -v "ScratchSize \[bytes/lane\]: 0" /tmp/apd_res_*_*.txt | grep -q Scratch; then echo "SCRATCH IN USE"; exit 1; fi
 echo "no scratch"
