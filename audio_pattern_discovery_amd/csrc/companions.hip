@@ -151,25 +151,38 @@ __global__ __launch_bounds__(256) void cepstrum_kernel(const CepsParams P)
     for (uint32_t e = threadIdx.x; e < K * K; e += blockDim.x) t_dct[e] = P.dct[e];
     for (uint32_t e = threadIdx.x; e < n_tw; e += blockDim.x) t_tw[e] = P.twiddle[e];
     __syncthreads();
-    // per wavefront: two complex buffers of N (ping-pong; the direct form uses the first as N real samples), mag[half], conv[K], ceps[K]
-    float *base = reinterpret_cast<float *>(t_tw + n_tw) + (size_t)wave * ((4 * N + half + 2 * K + 1u) & ~1u);
-    float2 *bufa = reinterpret_cast<float2 *>(base), *bufb = bufa + N;
-    float *mag = base + 4 * N, *conv = mag + half, *ceps = conv + K;
-    const uint64_t n_waves = (uint64_t)gridDim.x * 4u;
-    for (uint64_t frame = (uint64_t)blockIdx.x * 4u + wave; frame < P.n_frames; frame += n_waves) {
-        uint32_t lo = 0, hi = P.n_seq;                             // recording holding this frame: largest s with frame_off[s] <= frame
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (P.frame_off[mid] <= frame) lo = mid; else hi = mid; }
-        const uint64_t start = P.sample_off[lo] + (frame - P.frame_off[lo]) * P.step;   // i - fft_size, i = fft + t * step (:51-53)
+    // per wavefront: two complex buffers of N/2 (ping-pong; the direct form uses the first as N real samples), mag[half], conv[K], ceps[K]
+    float *base = reinterpret_cast<float *>(t_tw + n_tw) + (size_t)wave * ((2 * N + half + 2 * K + 1u) & ~1u);
+    float2 *bufa = reinterpret_cast<float2 *>(base), *bufb = bufa + half;
+    float *mag = base + 2 * N, *conv = mag + half, *ceps = conv + K;
+    // A wavefront takes a CONTIGUOUS run of frames: consecutive frames of a recording overlap (dft_step < dft_win: their samples
+    // come from L2 the second time) and the recording index only ever steps forward (one binary search per run, not per frame).
+    const uint64_t n_waves = (uint64_t)gridDim.x * 4u, per_wave = (P.n_frames + n_waves - 1) / n_waves;
+    const uint64_t f_begin = ((uint64_t)blockIdx.x * 4u + wave) * per_wave, f_end = min(f_begin + per_wave, P.n_frames);
+    uint32_t lo = 0;
+    if (f_begin < f_end) {
+        uint32_t hi = P.n_seq;                                     // recording holding the first frame: largest s with frame_off[s] <= frame
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (P.frame_off[mid] <= f_begin) lo = mid; else hi = mid; }
+    }
+    uint64_t next_off = f_begin < f_end ? P.frame_off[lo + 1] : 0, this_off = f_begin < f_end ? P.frame_off[lo] : 0, samp0 = f_begin < f_end ? P.sample_off[lo] : 0;
+    for (uint64_t frame = f_begin; frame < f_end; ++frame) {
+        while (frame >= next_off) { ++lo; this_off = next_off; next_off = P.frame_off[lo + 1]; samp0 = P.sample_off[lo]; }   // recordings without frames are skipped
+        const uint64_t start = samp0 + (frame - this_off) * P.step;   // i - fft_size, i = fft + t * step (:51-53)
         if (P.log2n) {
-            for (uint32_t s = lane; s < N; s += 64) bufa[s] = make_float2((float)P.samples[start + s] * t_ham[s], 0.0f);   // :55-59
+            // real input: the N samples are packed as M = N/2 complex values z[s] = x[2s] + i x[2s+1], one M-point FFT is
+            // run (half the butterflies and half the LDS traffic of an N-point transform of zero-imaginary data), and the
+            // N-point spectrum of the real signal follows from Z[k] and conj(Z[M-k]).
+            const uint32_t M = half, hm = M / 2;
+            for (uint32_t s = lane; s < M; s += 64)
+                bufa[s] = make_float2((float)P.samples[start + 2 * s] * t_ham[2 * s], (float)P.samples[start + 2 * s + 1] * t_ham[2 * s + 1]);   // :55-59
             APD_WAVE_LDS_FENCE();
             float2 *src = bufa, *dst = bufb;
-            for (uint32_t st = 0; st < P.log2n; ++st) {
+            for (uint32_t st = 0; st + 1 < P.log2n; ++st) {
                 const uint32_t Ns = 1u << st;
-                for (uint32_t j = lane; j < half; j += 64) {
+                for (uint32_t j = lane; j < hm; j += 64) {
                     const uint32_t k = j & (Ns - 1);
                     const float2 w = t_tw[k * (half / Ns)];        // exp(-2 pi i k / (2 Ns))
-                    const float2 p = src[j], q0 = src[j + half];
+                    const float2 p = src[j], q0 = src[j + hm];
                     const float2 q = make_float2(q0.x * w.x - q0.y * w.y, q0.x * w.y + q0.y * w.x);
                     const uint32_t idx = ((j - k) << 1) + k;
                     dst[idx] = make_float2(p.x + q.x, p.y + q.y);
@@ -178,9 +191,12 @@ __global__ __launch_bounds__(256) void cepstrum_kernel(const CepsParams P)
                 APD_WAVE_LDS_FENCE();
                 float2 *tmp = src; src = dst; dst = tmp;
             }
-            for (uint32_t k = lane; k < half; k += 64) {
-                const float2 v = src[k];
-                mag[k] = sqrtf(v.x * v.x + v.y * v.y);             // norm_sqr().sqrt() (:63)
+            for (uint32_t k = lane; k < M; k += 64) {
+                const float2 zk = src[k], zm = src[(M - k) & (M - 1)], w = t_tw[k];   // w = exp(-2 pi i k / N)
+                const float ax = 0.5f * (zk.x + zm.x), ay = 0.5f * (zk.y - zm.y);     // (Z[k] + conj Z[M-k]) / 2
+                const float bx = zk.x - zm.x, by = zk.y + zm.y;                       //  Z[k] - conj Z[M-k]
+                const float xr = ax + 0.5f * (w.x * by + w.y * bx), xi = ay - 0.5f * (w.x * bx - w.y * by);
+                mag[k] = sqrtf(xr * xr + xi * xi);                                    // norm_sqr().sqrt() (:63)
             }
         } else {
             float *win = base;                                     // N windowed samples
@@ -407,7 +423,7 @@ static int cepstrum_impl(apd_context *ctx, const int16_t *samples, const uint64_
     P.twiddle = reinterpret_cast<const float2 *>(d_tab + tw_off);
     P.out = on_device ? out : reinterpret_cast<float *>(pool + out_off);
     const size_t table_floats = tw_off + 2 * (size_t)n_tw;                               // the kernel lays its LDS out the same way
-    const size_t lds_bytes = (table_floats + 4 * ((4 * (size_t)fft_size + half + 2 * K + 1) & ~(size_t)1)) * sizeof(float);
+    const size_t lds_bytes = (table_floats + 4 * ((2 * (size_t)fft_size + half + 2 * K + 1) & ~(size_t)1)) * sizeof(float);
     if (lds_bytes > 160 * 1024) rc = APD_ERR_UNSUPPORTED;
     if (rc == APD_OK && lds_bytes > 64 * 1024)
         guard(hipFuncSetAttribute(reinterpret_cast<const void *>(cepstrum_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
