@@ -27,7 +27,7 @@ __global__ __launch_bounds__(64 * NW) void dtw_fused_wide(const AlignLaunch L)
     constexpr int R = (G <= 256) ? 512 : 1024;                   // row ring: R > 2U + G - 2
     constexpr int LPF = DP / 4, FPF = 64 / LPF, NFILL = (U + FPF - 1) / FPF;
     constexpr uint32_t FB = DP * 4u;
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     float *const xring = lds;                                     // [R][DP]
     float *const mb_y = xring + R * DP;                           // [NW + 1][DP]
     float *const mb_left = mb_y + (NW + 1) * DP;                  // [NW + 1][2]
@@ -136,13 +136,21 @@ __global__ __launch_bounds__(64 * NW) void dtw_fused_wide(const AlignLaunch L)
                 const int tau = tau0 + q;
                 const int r = q % S, e = (r + C) % S;
                 // seam traffic of this macro-step: hand the column frame down, publish the prefetched entering column
-                if (lane == 0) {
+                if (lane == 0) {                                   // 16-byte stores: one LDS instruction per four components
 #pragma unroll
-                    for (int k = 0; k < DN; ++k) mb_y[wv * DP + k] = yf[(r + 1) % S][k];
+                    for (int q4 = 0; q4 < LPF; ++q4) {
+                        apd_f32x4 t;
+                        t.x = yf[(r + 1) % S][4 * q4];
+                        t.y = (4 * q4 + 1 < DN) ? yf[(r + 1) % S][4 * q4 + 1] : 0.0f;
+                        t.z = (4 * q4 + 2 < DN) ? yf[(r + 1) % S][4 * q4 + 2] : 0.0f;
+                        t.w = (4 * q4 + 3 < DN) ? yf[(r + 1) % S][4 * q4 + 3] : 0.0f;
+                        *reinterpret_cast<apd_f32x4 *>(&mb_y[wv * DP + 4 * q4]) = t;
+                    }
                 }
                 if (pre_lane) mb_y[NW * DP + lane] = ypre;
                 ypre = pre_load(tau + 2);
-                const float lf1 = mb_left[wv * 2], lf2 = mb_left[wv * 2 + 1];       // written before the previous barrier
+                const float2 lf = *reinterpret_cast<const float2 *>(&mb_left[wv * 2]);   // written before the previous barrier
+                const float lf1 = lf.x, lf2 = lf.y;
                 // distances
                 float d[C];
                 if (HYBRID) {
@@ -176,13 +184,19 @@ __global__ __launch_bounds__(64 * NW) void dtw_fused_wide(const AlignLaunch L)
                     const float r2 = select_node<true>(prev2[1 % C], left2, prev2[0], d[0], pen, pen, pen, g2[0]);
                     prev1[0] = r1; prev2[0] = r2;
                     left1 = r1; left2 = r2;
-                    if (lane == 0) { mb_up[wv * 2] = r1; mb_up[wv * 2 + 1] = r2; }
+                    if (lane == 0) *reinterpret_cast<float2 *>(&mb_up[wv * 2]) = make_float2(r1, r2);
                 }
                 __syncthreads();                                  // barrier A
-                const float uf1 = mb_up[(wv + 1) * 2], uf2 = mb_up[(wv + 1) * 2 + 1];
-                const float upr1 = from_upper_lane(prev1[0], uf1), upr2 = from_upper_lane(prev2[0], uf2);
+                const float2 uf = *reinterpret_cast<const float2 *>(&mb_up[(wv + 1) * 2]);
+                const float upr1 = from_upper_lane(prev1[0], uf.x), upr2 = from_upper_lane(prev2[0], uf.y);
 #pragma unroll
-                for (int k = 0; k < DN; ++k) yf[e][k] = mb_y[(wv + 1) * DP + k];  // broadcast read into the dead slot: lane 63's hand-down
+                for (int q4 = 0; q4 < LPF; ++q4) {                // broadcast read into the dead slot: lane 63's hand-down
+                    const apd_f32x4 t = *reinterpret_cast<const apd_f32x4 *>(&mb_y[(wv + 1) * DP + 4 * q4]);
+                    yf[e][4 * q4] = t.x;
+                    if (4 * q4 + 1 < DN) yf[e][4 * q4 + 1] = t.y;
+                    if (4 * q4 + 2 < DN) yf[e][4 * q4 + 2] = t.z;
+                    if (4 * q4 + 3 < DN) yf[e][4 * q4 + 3] = t.w;
+                }
                 read_row(xs, tau + 1 - gl);                       // the row frame is dead: fetch the next one
 #pragma unroll
                 for (int c = 1; c < C; ++c) {
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(64 * NW) void dtw_fused_wide(const AlignLaunch L)
                     prev1[c] = r1; prev2[c] = r2;
                     left1 = r1; left2 = r2;
                 }
-                if (lane == 63) { mb_left[(wv + 1) * 2] = left1; mb_left[(wv + 1) * 2 + 1] = left2; }
+                if (lane == 63) *reinterpret_cast<float2 *>(&mb_left[(wv + 1) * 2]) = make_float2(left1, left2);
                 if (SLOW) {
                     if (tau == gl) {
 #pragma unroll
