@@ -146,7 +146,10 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     constexpr int R = (G == 64) ? 128 : 64;                      // G = 32, U <= 10: 2U + G - 2 = 50 < 64
     constexpr int LPF = DP / 4;                                  // lanes (16-byte pieces) per frame
     constexpr int FPF = 64 / LPF;                                // frames per wave-wide fill
-    __shared__ float xring_all[4][R * DP];
+    // ring rows are RS = DP + 4 floats apart: the 16 lanes of a ds_read_b128 group read 16 consecutive rows, and a stride of
+    // 16 floats would put every fourth of them on the same banks (4-way conflict); 20 floats spreads them over all 64
+    constexpr int RS = DP + 4;
+    __shared__ float xring_all[4][R * RS];
     float *const xring = xring_all[threadIdx.x >> 6];
     // sequence a (and its length) is the same for every sweeping group of the wave
     const int lead = __builtin_ctzll(__ballot(sweep));
@@ -219,11 +222,11 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
         for (int f = 0; f < NFILL; ++f) {
             const int fi = f * FPF + fill_f;
             if ((fill_f < FPF) & (fi < U))
-                *reinterpret_cast<apd_f32x4 *>(&xring[((first_row + fi) & (R - 1)) * DP + 4 * fill_q]) = regs[f];
+                *reinterpret_cast<apd_f32x4 *>(&xring[((first_row + fi) & (R - 1)) * RS + 4 * fill_q]) = regs[f];
         }
     };
     for (int e = lane; e < G * DP; e += 64)                      // rows <= 0: -INF components, or (hybrid) zeros with norm +INF
-        xring[((-(e / DP)) & (R - 1)) * DP + (e % DP)] = HYBRID ? ((e % DP) == D ? APD_INF : 0.0f) : -APD_INF;
+        xring[((-(e / DP)) & (R - 1)) * RS + (e % DP)] = HYBRID ? ((e % DP) == D ? APD_INF : 0.0f) : -APD_INF;
     {
         apd_f32x4 regs[NFILL];
         fill_load(1, regs);
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     }
     asm volatile("" ::: "memory");
     auto read_row = [&](float (&dst)[DN], int row) __attribute__((always_inline)) {
-        const float *p = &xring[(row & (R - 1)) * DP];
+        const float *p = &xring[(row & (R - 1)) * RS];
 #pragma unroll
         for (int q = 0; q < LPF; ++q) {
             const apd_f32x4 t = *reinterpret_cast<const apd_f32x4 *>(p + 4 * q);

@@ -214,6 +214,14 @@ def main():
         try:
             comm = sharding.Comm(ctx, box[0], rank, world)
             ranks_seen = comm.count()
+            # one small all-gather now: RCCL sets its channels up on first use, which must not land in a timed step (--warmup 0)
+            warm_src = torch.full((256,), float(rank), dtype=torch.float32, device=dev)
+            warm_dst = torch.empty(256 * world, dtype=torch.float32, device=dev)
+            _lib.check(L.apd_all_gather_async(ctx.handle, comm.handle, C.c_void_p(warm_src.data_ptr()), C.c_void_p(warm_dst.data_ptr()), 256),
+                       ctx.handle)
+            ctx.synchronize()
+            if not torch.equal(warm_dst.view(world, 256)[:, 0].cpu(), torch.arange(world, dtype=torch.float32)):
+                raise RuntimeError("all-gather returned the slabs out of rank order")
         except Exception as exc:                                         # noqa: BLE001 -- any failure: agree on the fallback
             sys.stderr.write("[bench] rank %d: apd_comm_create failed (%s); falling back to torch.distributed nccl\n" % (rank, exc))
             ok = 0
