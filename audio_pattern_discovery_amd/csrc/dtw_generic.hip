@@ -26,6 +26,7 @@
 // dtw_systolic.h holds the production kernel.
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include "dtw_common.h"
 
 namespace apd {
@@ -110,33 +111,85 @@ __global__ __launch_bounds__(64) void dtw_fused_generic(const AlignLaunch L, int
 // ceil4(dim + 1) floats: the dim components, then the squared norm sum_k x_k^2 (slot dim), then zeros.  Sentinel H has
 // zero components and norm +INF (hybrid distances), sentinel E has +INF components (difference-form distances).
 // ------------------------------------------------------------------------------------------------
-__global__ void pad_frames_kernel(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ seq_off,
+__global__ __launch_bounds__(256) void pad_frames_kernel(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ seq_off,
                                   const uint32_t *__restrict__ src_off, uint32_t n_seq, uint64_t n_frames_padded, uint32_t src_dim,
                                   uint32_t dim, uint32_t dpad, uint32_t *__restrict__ flags, float *__restrict__ seq_nmax)
 {
-    const uint64_t total = n_frames_padded * dpad;
+    // One thread per 16-byte piece of a resident frame (dpad / 4 pieces per frame, dpad / 4 consecutive lanes -- a power of
+    // two up to 8 for the instantiated dimensions, any count otherwise): one search for the frame's sequence per piece,
+    // contiguous reads of the source frame, one aligned 16-byte store; the squared norm is summed in f64 over the lanes of
+    // the frame.  (The first version ran one thread, one search and one 4-byte store per FLOAT: 0.48 TB/s.)
+    const uint32_t ppf = dpad / 4;                                // pieces per frame
+    const uint64_t total = n_frames_padded * ppf;
     bool nonfinite = false;
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t f = (uint32_t)(e / dpad);
-        const uint32_t k = (uint32_t)(e - (uint64_t)f * dpad);
-        uint32_t lo = 0, hi = n_seq;                          // largest s with seq_off[s] <= f
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seq_off[mid] <= f) lo = mid; else hi = mid; }
-        const bool sent_e = (f + 1 == seq_off[lo + 1]), sent_h = (f + 2 == seq_off[lo + 1]);
-        float v = 0.0f;
-        if (sent_e) v = (k <= dim) ? APD_INF : 0.0f;
-        else if (sent_h) v = (k == dim) ? APD_INF : 0.0f;
-        else {
+    const bool shuffle_ok = (ppf & (ppf - 1)) == 0 && ppf <= 64;  // the lanes of a frame sit in one wavefront, aligned
+    for (uint64_t e0 = (uint64_t)blockIdx.x * blockDim.x; e0 < total; e0 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t e = e0 + threadIdx.x;
+        const bool live = e < total;
+        const uint32_t f = live ? (uint32_t)(e / ppf) : 0u, q = live ? (uint32_t)(e - (uint64_t)f * ppf) : 0u;
+        // largest s with seq_off[s] <= f: one search per wavefront (for its first frame), then a step or two forward per lane
+        const uint32_t f_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
+        uint32_t lo = 0, hi = n_seq;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seq_off[mid] <= f_first) lo = mid; else hi = mid; }
+        while (live && lo + 1 < n_seq && seq_off[lo + 1] <= f) ++lo;
+        const bool sent_e = live && (f + 1 == seq_off[lo + 1]), sent_h = live && (f + 2 == seq_off[lo + 1]);
+        const bool real = live && !sent_e && !sent_h;
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        double part = 0.0;                                        // this piece's share of sum_k x_k^2
+        if (real) {
             const float *fr = src + (uint64_t)(src_off[lo] + (f - seq_off[lo])) * src_dim;
-            if (k < src_dim) { v = fr[k]; nonfinite |= !(__builtin_fabsf(v) < APD_INF); }   // NaN or +-INF; components src_dim .. dim - 1 stay zero
-            else if (k == dim) {
-                double acc = 0.0;
-                for (uint32_t t = 0; t < src_dim; ++t) acc += (double)fr[t] * (double)fr[t];
-                v = (float)acc;
-                // largest norm of the sequence: non-negative floats order like their bit patterns (a NaN norm flags the batch anyway)
-                if (v == v) atomicMax(reinterpret_cast<unsigned int *>(&seq_nmax[lo]), __builtin_bit_cast(unsigned int, v));
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t k = 4 * q + i;
+                if (k < src_dim) {                                // components src_dim .. dim - 1 stay zero
+                    v[i] = fr[k];
+                    nonfinite |= !(__builtin_fabsf(v[i]) < APD_INF);   // NaN or +-INF
+                    part += (double)v[i] * (double)v[i];
+                }
             }
         }
-        dst[e] = v;
+        double norm = part;
+        if (ppf == 4) {                                           // D <= 14: the four pieces of a frame are one DPP quad
+            auto quad_swap = [](double x, auto ctrl) __attribute__((always_inline)) {
+                constexpr int CTRL = decltype(ctrl)::value;
+                const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+                const unsigned int lo32 = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)b, CTRL, 0xf, 0xf, false);
+                const unsigned int hi32 = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(b >> 32), CTRL, 0xf, 0xf, false);
+                return __builtin_bit_cast(double, ((unsigned long long)hi32 << 32) | lo32);
+            };
+            norm += quad_swap(norm, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+            norm += quad_swap(norm, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+        } else if (shuffle_ok) {
+            for (uint32_t o = 1; o < ppf; o <<= 1) norm += __shfl_xor(norm, (int)o);
+        } else if (real) {                                        // generic dimension: the piece holding slot `dim` re-reads the frame
+            norm = 0.0;
+            if (dim / 4 == q) {
+                const float *fr = src + (uint64_t)(src_off[lo] + (f - seq_off[lo])) * src_dim;
+                for (uint32_t t = 0; t < src_dim; ++t) norm += (double)fr[t] * (double)fr[t];
+            }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            const uint32_t k = 4 * q + i;
+            if (sent_e) v[i] = (k <= dim) ? APD_INF : 0.0f;
+            else if (sent_h) v[i] = (k == dim) ? APD_INF : 0.0f;
+            else if (real && k == dim) v[i] = (float)norm;
+        }
+        {
+            // largest norm of the sequence: non-negative floats order like their bit patterns (a NaN norm flags the batch anyway).
+            // The frames of a wavefront almost always belong to one sequence: one atomic per wavefront then, not one per frame.
+            const float mine = (real && dim / 4 == q && norm == norm) ? (float)norm : 0.0f;
+            const bool has = real && dim / 4 == q;
+            const uint32_t lo_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+            const unsigned long long any_has = __ballot(has);
+            if (__ballot(has && lo != lo_first) == 0ull) {
+                float m = mine;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+                if ((threadIdx.x & 63) == 0 && any_has != 0ull) atomicMax(reinterpret_cast<unsigned int *>(&seq_nmax[lo_first]), __builtin_bit_cast(unsigned int, m));
+            } else if (has) atomicMax(reinterpret_cast<unsigned int *>(&seq_nmax[lo]), __builtin_bit_cast(unsigned int, mine));
+        }
+        if (live) *reinterpret_cast<float4 *>(dst + e * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
     // the fast kernels assume finite features (fminf-based select, +INF sentinels, norm expansion): a batch with a NaN or an
     // infinity anywhere is routed to the literal kernel, where NaN compares false and takes MATCH as in alignments.rs:153-159
@@ -200,7 +253,7 @@ hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_of
                       hipStream_t stream)
 {
     if (n_frames_padded == 0) return hipSuccess;
-    const uint64_t total = n_frames_padded * dpad;
+    const uint64_t total = n_frames_padded * (dpad / 4);
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 16384);
     hipLaunchKernelGGL(pad_frames_kernel, dim3(blocks), dim3(256), 0, stream, d_src, d_dst, d_seq_off, d_src_off, n_seq, n_frames_padded,
                        src_dim, dim, dpad, d_flags, d_seq_nmax);
