@@ -132,6 +132,8 @@ extern "C" int apd_destroy(apd_context *ctx)
     hipStreamSynchronize(ctx->stream);
     for (apd_batch *b : ctx->batches) { release_batch_device_memory(b); b->ctx = nullptr; }   // orphans: see apd_batch_destroy
     ctx->batches.clear();
+    for (apd_comm *c : ctx->comms) apd::orphan_comm(c);
+    ctx->comms.clear();
     if (ctx->ws_tiles) hipFree(ctx->ws_tiles);
     if (ctx->ws_slab) hipFree(ctx->ws_slab);
     if (ctx->ws_misc) hipFree(ctx->ws_misc);

@@ -74,6 +74,9 @@ hipError_t launch_unpack(const float *d_gathered, float *d_out, const uint32_t *
                          uint64_t slab_floats, const uint32_t *d_flags, uint32_t *d_status, hipStream_t stream);
 hipError_t launch_selftest(int *d_result, hipStream_t stream);
 
+// comm.hip: called by apd_destroy for every communicator still alive on the context
+void orphan_comm(apd_comm *comm);
+
 // numerics.rs:125-133 on a device array (clustering.hip): radix select of the k-th smallest non-NaN value.
 int device_select(apd_context *ctx, const float *d_x, uint64_t len, uint64_t k, float *value);
 uint64_t percentile_index(uint64_t len, float perc);
@@ -110,6 +113,9 @@ struct apd_context {
     // batches created on this context and not yet destroyed: apd_destroy releases their device memory and orphans them, so
     // that a later apd_batch_destroy (destruction order is the caller's, e.g. a garbage collector's) only frees the host part
     std::set<apd_batch *> batches;
+    // communicators made on this context and not yet destroyed: apd_destroy tears their RCCL side down and orphans them, so
+    // that a later apd_comm_destroy only frees the host part (same contract as for batches)
+    std::set<apd_comm *> comms;
     bool timed = false;
     int variant = 0;
     int distance_mode = 1;            // 0 exact differences, 1 hybrid

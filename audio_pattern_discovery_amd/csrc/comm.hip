@@ -75,16 +75,28 @@ extern "C" int apd_comm_create(apd_context *ctx, const void *id_bytes, uint32_t 
         delete c;
         return APD_ERR_COMM;
     }
+    ctx->comms.insert(c);
     *out = c;
     return APD_OK;
 }
 
+namespace apd {
+void orphan_comm(apd_comm *c)                                            // the context is going away (apd_destroy)
+{
+    if (c->comm) ncclCommDestroy(c->comm);
+    c->comm = nullptr;
+    c->ctx = nullptr;
+}
+}  // namespace apd
+
 extern "C" int apd_comm_destroy(apd_comm *c)
 {
     if (!c) return APD_ERR_INVALID_ARG;
-    if (c->comm) {
-        if (c->ctx) { hipSetDevice(c->ctx->device); hipStreamSynchronize(c->ctx->stream); }
-        ncclCommDestroy(c->comm);
+    if (c->ctx) {                                                        // else: orphaned by apd_destroy, RCCL side already gone
+        hipSetDevice(c->ctx->device);
+        hipStreamSynchronize(c->ctx->stream);
+        if (c->comm) ncclCommDestroy(c->comm);
+        c->ctx->comms.erase(c);
     }
     delete c;
     return APD_OK;
@@ -92,7 +104,7 @@ extern "C" int apd_comm_destroy(apd_comm *c)
 
 extern "C" int apd_comm_count(const apd_comm *c, uint32_t *world)
 {
-    if (!c || !world) return APD_ERR_INVALID_ARG;
+    if (!c || !world || !c->comm) return APD_ERR_INVALID_ARG;
     int n = 0;
     NCCL_TRY(c->ctx, ncclCommCount(c->comm, &n));
     *world = (uint32_t)n;
@@ -101,7 +113,7 @@ extern "C" int apd_comm_count(const apd_comm *c, uint32_t *world)
 
 extern "C" int apd_comm_rank(const apd_comm *c, uint32_t *rank)
 {
-    if (!c || !rank) return APD_ERR_INVALID_ARG;
+    if (!c || !rank || !c->comm) return APD_ERR_INVALID_ARG;
     int r = 0;
     NCCL_TRY(c->ctx, ncclCommUserRank(c->comm, &r));
     *rank = (uint32_t)r;

@@ -74,8 +74,9 @@ typedef struct apd_cluster_op {
 
 /* ---- context ------------------------------------------------------------------------- */
 int apd_create(int device, apd_context **ctx);
-/* Also releases the device memory of every batch still alive on the context; such a batch may (and must, for its host
- * part) still be passed to apd_batch_destroy afterwards, in any order, and is refused by every other call. */
+/* Also releases the device memory of every batch, and the RCCL side of every communicator, still alive on the context; such
+ * a batch / communicator may (and must, for its host part) still be passed to apd_batch_destroy / apd_comm_destroy
+ * afterwards, in any order, and is refused by every other call. */
 int apd_destroy(apd_context *ctx);
 /* Run on the caller's hipStream_t (e.g. torch's current stream) instead of the context's own. */
 int apd_set_stream(apd_context *ctx, void *hip_stream);

@@ -177,15 +177,15 @@ class AlignmentWorkers {
     {
         const std::size_t n = this->data.size();
         result.assign(n * n, 0.0f);
-        std::vector<uint64_t> offsets(n + 1, 0);
-        std::vector<float> frames;
-        const uint32_t dim = n ? (uint32_t)this->data[0].n_bins : 1;
+        offsets.assign(n + 1, 0);
+        dim = n ? (uint32_t)this->data[0].n_bins : 1;
         for (std::size_t s = 0; s < n; ++s) {
             if (this->data[s].n_bins != dim) throw Error(APD_ERR_INVALID_ARG, "sequences must share n_bins");
             offsets[s + 1] = offsets[s] + this->data[s].len();
             frames.insert(frames.end(), this->data[s].frames.begin(), this->data[s].frames.end());
         }
-        check(apd_batch_create(ctx_.get(), frames.data(), offsets.data(), (uint32_t)n, dim ? dim : 1, 0, &batch_), ctx_.get());
+        if (dim == 0) dim = 1;
+        check(apd_batch_create(ctx_.get(), frames.data(), offsets.data(), (uint32_t)n, dim, 0, &batch_), ctx_.get());
     }
     ~AlignmentWorkers() { if (batch_) apd_batch_destroy(batch_); }
     AlignmentWorkers(const AlignmentWorkers &) = delete;
@@ -195,11 +195,24 @@ class AlignmentWorkers {
         const apd_align_config c = params.config();
         check(apd_align_all(ctx_.get(), batch_, &c, result.data()), ctx_.get());
     }
+    // The same over several GPUs of one node (the reference's `alignment_workers` threads, alignments.rs:33-41, become devices):
+    // pair tiles sharded over `devices`, one RCCL all-gather inside the library.  Returns the ranks RCCL saw.
+    uint32_t align_all(const Discovery &params, const std::vector<int> &devices)
+    {
+        const apd_align_config c = params.config();
+        uint32_t seen = 0;
+        check(apd_align_all_multi(devices.data(), (uint32_t)devices.size(), frames.data(), offsets.data(), (uint32_t)data.size(), dim, &c,
+                                  result.data(), &seen));
+        return seen;
+    }
     std::vector<NDSequence> data;
     std::vector<float> result;                                                       // n*n row-major, diagonal 0.0
   private:
     Context &ctx_;
     apd_batch *batch_ = nullptr;
+    std::vector<float> frames;                                                       // packed [sum len][dim], kept for the multi-device entry
+    std::vector<uint64_t> offsets;
+    uint32_t dim = 1;
 };
 
 enum class Merge { Sequence2Sequence = 0, Sequence2Cluster = 1, Cluster2Sequence = 2, Cluster2Cluster = 3 };   // clustering.rs:8-13

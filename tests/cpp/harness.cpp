@@ -6,6 +6,7 @@
 //              parameters come from the TOML file, every sequence goes through AutoEncoder::from_file(..) -> encoded() first
 //              (main.rs:142-161), and the weight file is written back with save_file and compared byte for byte
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 
@@ -52,6 +53,11 @@ int main(int argc, char **argv)
         std::printf("dist");
         for (float v : workers.result) std::printf(" %.9g", v);
         std::printf("\n");
+        {   // the multi-device entry with the one device a test box has: same bits, one rank
+            const std::vector<float> single = workers.result;
+            const uint32_t seen = workers.align_all(cfg, std::vector<int>{0});
+            std::printf("multi %u %d\n", seen, (int)(std::memcmp(single.data(), workers.result.data(), single.size() * sizeof(float)) == 0));
+        }
         auto res = apd::AgglomerativeClustering::clustering(ctx, workers.result, n, cfg.clustering_percentile);
         for (const auto &o : res.first) std::printf("op %zu %zu %zu %.9g %d\n", o.merge_i, o.merge_j, o.into, o.distance, (int)o.operation);
         std::printf("roots");

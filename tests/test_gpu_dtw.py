@@ -652,3 +652,10 @@ def test_sharded_async_through_a_library_owned_communicator(ctx, oracle, apd):
     ctx.synchronize()
     assert torch.equal(src, dst)
     comm.close()
+    # destruction order is the caller's: a context may go before its communicator (and its batches)
+    ctx2 = apd.Context(0)
+    comm2 = sharding.Comm(ctx2, sharding.Comm.unique_id(), 0, 1)
+    ctx2.close()
+    with pytest.raises(apd.ApdError):
+        comm2.count()                                                    # orphaned: refused
+    comm2.close()
