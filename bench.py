@@ -384,9 +384,10 @@ def main():
             roots = np.zeros(n, dtype=np.uint32)
             n_ops, n_roots, thr = C.c_uint32(0), C.c_uint32(0), C.c_float(0)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            _lib.check(L.apd_clustering(ctx.handle, C.c_void_p(d_out.data_ptr()), 1, n, 0.05, ops, C.byref(n_ops),
-                                        roots.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n_roots), C.byref(thr)), ctx.handle)
+            cl_ctx = _lib.Context(dev_index)                         # a context with its own stream: the merge loop is replayed as a hipGraph,
+            t0 = time.perf_counter()                                 # which the legacy default stream (torch's current one) cannot capture
+            _lib.check(L.apd_clustering(cl_ctx.handle, C.c_void_p(d_out.data_ptr()), 1, n, 0.05, ops, C.byref(n_ops),
+                                        roots.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n_roots), C.byref(thr)), cl_ctx.handle)
             line["clustering"] = {"seconds": time.perf_counter() - t0, "merges": int(n_ops.value), "roots": int(n_roots.value),
                                   "threshold": float(thr.value), "percentile": 0.05,
                                   "note": "apd_clustering on the resident matrix: radix-select threshold + UPGMA (clustering.rs:81-110)"}
