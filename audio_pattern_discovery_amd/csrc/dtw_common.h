@@ -119,6 +119,7 @@ struct PairInfo {
     int slot_a, slot_b;
     uint32_t slab_tile;     // position of the tile in the rank's slab
     float nmax_b;           // largest squared frame norm of sequence b
+    float nmax_ab;          // ... of either sequence (kernels that may take their columns from a or b)
     bool valid;
 };
 
@@ -130,6 +131,7 @@ __device__ __forceinline__ PairInfo decode_pair(const AlignLaunch &L, uint32_t t
     p.valid = false;
     p.slab_tile = 0;
     p.nmax_b = 0.0f;
+    p.nmax_ab = 0.0f;
     p.A = p.B = L.d_frames; p.n = p.m = 2; p.w = 2;
     if (tile >= L.n_tiles) return p;
     const uint4 t = L.d_tiles[tile];
@@ -144,6 +146,7 @@ __device__ __forceinline__ PairInfo decode_pair(const AlignLaunch &L, uint32_t t
     p.B = L.d_frames + (uint64_t)ob * L.dpad;
     p.w = pair_w(L.band, p.n, p.m);
     p.nmax_b = L.d_seq_nmax[b];
+    p.nmax_ab = fmaxf(L.d_seq_nmax[a], p.nmax_b);
     return p;
 }
 

@@ -64,8 +64,8 @@ __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
         b_off = __builtin_amdgcn_readfirstlane(b_off);
     }
     static_assert(!GENERAL_PEN || (BANDED && !HYBRID), "general penalties: two DPs on strict distances");
-    float pen = L.band.mat, tau_thr = L.tau, p_ins = L.band.ins, p_del = L.band.del;
-    asm volatile("" : "+v"(pen), "+v"(tau_thr), "+v"(p_ins), "+v"(p_del));
+    float pen = L.band.mat, tau_thr = L.tau, p_ins = L.band.ins, p_del = L.band.del, nmax_ab = P.nmax_ab;
+    asm volatile("" : "+v"(pen), "+v"(tau_thr), "+v"(p_ins), "+v"(p_del), "+v"(nmax_ab));
     // BANDED: the band binds.  Band offset u = j - i + w; score(a, b) lives on u in [0, 2w-1], score(b, a) -- the swapped
     // pair's recurrence transposed, the same select for equal penalties -- on u in [1, 2w] (see dtw_generic.hip).  Cells
     // outside get a local distance of +INF, which makes the node +INF whatever its predecessors are.
@@ -142,13 +142,17 @@ __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
                 const int tau = tau0 + q;
                 float d[CW];
                 if (HYBRID) {
-                    bool any = false;
+                    // one superset test per macro-step instead of one per cell (see dtw_systolic.h)
 #pragma unroll
                     for (int c = 0; c < CW; ++c) {
                         float sc;
                         d[c] = frame_sq_expanded<D>(xs, yf[c], sc);
-                        any |= d[c] < sc * tau_thr;
                     }
+                    float dmin = d[0];
+#pragma unroll
+                    for (int c = 1; c + 1 < CW; c += 2) dmin = __builtin_fminf(__builtin_fminf(dmin, d[c]), d[c + 1]);
+                    if (CW % 2 == 0) dmin = __builtin_fminf(dmin, d[CW - 1]);
+                    const bool any = dmin < (xs[D] + nmax_ab) * tau_thr;
                     if (__ballot(any) != 0ull) {
 #pragma unroll
                         for (int c = 0; c < CW; ++c) {

@@ -43,8 +43,8 @@ __global__ __launch_bounds__(64 * NW) void dtw_fused_wide(const AlignLaunch L)
     const int n = P.n, m = P.m, w = P.w;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)L.d_frames, 0, L.frames_bytes, 0x00020000);
     const uint32_t a_off = (uint32_t)(P.A - L.d_frames) * 4u, b_off = (uint32_t)(P.B - L.d_frames) * 4u;
-    float pen = L.band.mat, tau_thr = L.tau;                      // uniform penalties only (the dispatcher guarantees it)
-    asm volatile("" : "+v"(pen), "+v"(tau_thr));
+    float pen = L.band.mat, tau_thr = L.tau, nmax_ab = P.nmax_ab;   // uniform penalties only (the dispatcher guarantees it)
+    asm volatile("" : "+v"(pen), "+v"(tau_thr), "+v"(nmax_ab));
     const int u0 = C * gl, two_w = 2 * w;
     bool g1[C], g2[C];
 #pragma unroll
@@ -154,13 +154,17 @@ __global__ __launch_bounds__(64 * NW) void dtw_fused_wide(const AlignLaunch L)
                 // distances
                 float d[C];
                 if (HYBRID) {
-                    bool any = false;
+                    // one superset test per macro-step instead of one per cell (see dtw_systolic.h)
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
                         float sc;
                         d[c] = frame_sq_expanded<D>(xs, yf[(r + c) % S], sc);
-                        any |= d[c] < sc * tau_thr;
                     }
+                    float dmin = d[0];
+#pragma unroll
+                    for (int c = 1; c + 1 < C; c += 2) dmin = __builtin_fminf(__builtin_fminf(dmin, d[c]), d[c + 1]);
+                    if (C % 2 == 0) dmin = __builtin_fminf(dmin, d[C - 1]);
+                    const bool any = dmin < (xs[D] + nmax_ab) * tau_thr;
                     if (__ballot(any) != 0ull) {
 #pragma unroll
                         for (int c = 0; c < C; ++c) {
