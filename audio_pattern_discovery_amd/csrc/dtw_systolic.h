@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                     for (int c = 1; c + 1 < C; c += 2) dmin = __builtin_fminf(__builtin_fminf(dmin, d[c]), d[c + 1]);
                     if (C % 2 == 0) dmin = __builtin_fminf(dmin, d[C - 1]);
                     const bool any = (APD_ABLATE & 128) ? false : dmin < (xs[xa][D] + nmax_b) * tau_thr;
-                    if (__ballot(any) != 0ull) {
+                    if (__builtin_expect(__ballot(any) != 0ull, 0)) {   // rare: placed out of the hot instruction stream
 #pragma unroll
                         for (int c = 0; c < C; ++c) {
                             const float sc = xs[xa][D] + yf[(r + c) % S][D];

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64 * NW) void dtw_fused_wide(const AlignLaunch L)
                     for (int c = 1; c + 1 < C; c += 2) dmin = __builtin_fminf(__builtin_fminf(dmin, d[c]), d[c + 1]);
                     if (C % 2 == 0) dmin = __builtin_fminf(dmin, d[C - 1]);
                     const bool any = dmin < (xs[D] + nmax_ab) * tau_thr;
-                    if (__ballot(any) != 0ull) {
+                    if (__builtin_expect(__ballot(any) != 0ull, 0)) {   // rare: placed out of the hot instruction stream
 #pragma unroll
                         for (int c = 0; c < C; ++c) {
                             const float sc = xs[D] + yf[(r + c) % S][D];
