@@ -53,6 +53,29 @@ __device__ __forceinline__ float group_from_upper(float v, float fill, int gl)
     return gl == G - 1 ? fill : t;
 }
 
+// The same shifts for values whose group-edge lane does not care what it receives (or is known to receive +INF from the
+// other end of the group): rotations, row_ror:1 0x121 / row_ror:15 0x12F, wave_ror:1 0x13C / wave_rol:1 0x134.  Every lane
+// has a source, so no `fill` register has to be materialised before the move (one v_mov less per exchange).
+template <int CTRL>
+__device__ __forceinline__ float dpp_rotate(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int G>
+__device__ __forceinline__ float group_from_lower_wrap(float v, float fill, int gl)
+{
+    if (G == 16) return dpp_rotate<0x121>(v);
+    if (G == 64) return dpp_rotate<0x13C>(v);
+    return group_from_lower<G>(v, fill, gl);
+}
+template <int G>
+__device__ __forceinline__ float group_from_upper_wrap(float v, float fill, int gl)
+{
+    if (G == 16) return dpp_rotate<0x12F>(v);
+    if (G == 64) return dpp_rotate<0x134>(v);
+    return group_from_upper<G>(v, fill, gl);
+}
+
 __device__ __forceinline__ uint32_t band_from_pct(float pct, uint32_t len)
 {
     float p = pct * (float)len;                 // discovery.rs:40, one f32 rounding

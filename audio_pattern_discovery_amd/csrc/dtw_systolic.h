@@ -100,6 +100,29 @@ __device__ __forceinline__ float frame_sq_expanded(const float (&x)[D + 1], cons
     s_out = x[D] + y[D];
     return __builtin_fmaf(-2.0f, dot, s_out);
 }
+// The same with the row frame pre-scaled: xm[k] = -2 x[k] (done once per row when the wave stages it in LDS), xm[D] = |x|^2.
+// |x|^2 + |y|^2 + sum xm_k y_k: one add and D v_fmac -- the multiply that opens the dot product and the closing fma(-2, ., .) are gone.
+template <int D>
+__device__ __forceinline__ float frame_sq_expanded_pre(const float (&xm)[D + 1], const float (&y)[D + 1])
+{
+    float acc = xm[D] + y[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) acc = __builtin_fmaf(xm[k], y[k], acc);
+    return acc;
+}
+// Difference form from the pre-scaled row frame: fma(-0.5, xm_k, -y_k) is x_k - y_k with its one rounding (the scaling is exact).
+template <int D>
+__device__ __forceinline__ float frame_sq_exact_pre(const float (&xm)[D + 1], const float (&y)[D + 1])
+{
+    float t = __builtin_fmaf(-0.5f, xm[0], -y[0]);
+    float acc = t * t;
+#pragma unroll
+    for (int k = 1; k < D; ++k) {
+        t = __builtin_fmaf(-0.5f, xm[k], -y[k]);
+        acc = __builtin_fmaf(t, t, acc);
+    }
+    return acc;
+}
 template <int D>
 __device__ __forceinline__ float frame_sq_exact(const float (&x)[D + 1], const float (&y)[D + 1])
 {
@@ -149,7 +172,11 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     // ring rows are RS = DP + 4 floats apart: the 16 lanes of a ds_read_b128 group read 16 consecutive rows, and a stride of
     // 16 floats would put every fourth of them on the same banks (4-way conflict); 20 floats spreads them over all 64
     constexpr int RS = DP + 4;
-    __shared__ float xring_all[4][R * RS];
+    // S = C + 1 and U (rows per refill) are fixed further down; the ring carries a copy of its first U rows behind row R - 1, so
+    // that the U consecutive rows a lane reads during one unrolled block are contiguous: one address per block, the rest are
+    // immediate offsets of the ds_read
+    constexpr int U_ROWS = ((C + 1) % 2 == 0) ? (C + 1) : 2 * (C + 1);
+    __shared__ float xring_all[4][(R + U_ROWS) * RS];
     float *const xring = xring_all[threadIdx.x >> 6];
     // sequence a (and its length) is the same for every sweeping group of the wave
     const int lead = __builtin_ctzll(__ballot(sweep));
@@ -186,6 +213,7 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     // macro-steps every slot keeps its physical registers (no copies on the back-edge).
     constexpr int S = C + 1;
     constexpr int U = (S % 2 == 0) ? S : 2 * S;
+    static_assert(U == U_ROWS, "ring copy sized for another unroll");
     const int total_r = ((total + U - 1) / U) * U;
     const int a_end = min(((G + U - 1) / U) * U, total_r);
     const int b_end = min(max((min_rows / U) * U, a_end), total_r);
@@ -221,12 +249,27 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
 #pragma unroll
         for (int f = 0; f < NFILL; ++f) {
             const int fi = f * FPF + fill_f;
-            if ((fill_f < FPF) & (fi < U))
-                *reinterpret_cast<apd_f32x4 *>(&xring[((first_row + fi) & (R - 1)) * RS + 4 * fill_q]) = regs[f];
+            if ((fill_f < FPF) & (fi < U)) {
+                apd_f32x4 v = regs[f];
+                if (HYBRID) {                                    // stage -2 x (the norm slot stays): see frame_sq_expanded_pre
+                    const bool np = fill_q == D / 4;             // the piece that holds the norm
+                    v.x = (np && D % 4 == 0) ? v.x : -2.0f * v.x;
+                    v.y = (np && D % 4 == 1) ? v.y : -2.0f * v.y;
+                    v.z = (np && D % 4 == 2) ? v.z : -2.0f * v.z;
+                    v.w = (np && D % 4 == 3) ? v.w : -2.0f * v.w;
+                }
+                const int slot = (first_row + fi) & (R - 1);
+                *reinterpret_cast<apd_f32x4 *>(&xring[slot * RS + 4 * fill_q]) = v;
+                if (slot < U) *reinterpret_cast<apd_f32x4 *>(&xring[(slot + R) * RS + 4 * fill_q]) = v;   // the copy behind the ring
+            }
         }
     };
-    for (int e = lane; e < G * DP; e += 64)                      // rows <= 0: -INF components, or (hybrid) zeros with norm +INF
-        xring[((-(e / DP)) & (R - 1)) * RS + (e % DP)] = HYBRID ? ((e % DP) == D ? APD_INF : 0.0f) : -APD_INF;
+    for (int e = lane; e < G * DP; e += 64) {                    // rows <= 0: -INF components, or (hybrid) zeros with norm +INF
+        const int slot = (-(e / DP)) & (R - 1);
+        const float v = HYBRID ? ((e % DP) == D ? APD_INF : 0.0f) : -APD_INF;
+        xring[slot * RS + (e % DP)] = v;
+        if (slot < U) xring[(slot + R) * RS + (e % DP)] = v;
+    }
     {
         apd_f32x4 regs[NFILL];
         fill_load(1, regs);
@@ -235,6 +278,16 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     asm volatile("" ::: "memory");
     auto read_row = [&](float (&dst)[DN], int row) __attribute__((always_inline)) {
         const float *p = &xring[(row & (R - 1)) * RS];
+#pragma unroll
+        for (int q = 0; q < LPF; ++q) {
+            const apd_f32x4 t = *reinterpret_cast<const apd_f32x4 *>(p + 4 * q);
+            if (4 * q + 0 < DN) dst[4 * q + 0] = t.x;
+            if (4 * q + 1 < DN) dst[4 * q + 1] = t.y;
+            if (4 * q + 2 < DN) dst[4 * q + 2] = t.z;
+            if (4 * q + 3 < DN) dst[4 * q + 3] = t.w;
+        }
+    };
+    auto read_row_at = [&](float (&dst)[DN], const float *p) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < LPF; ++q) {
             const apd_f32x4 t = *reinterpret_cast<const apd_f32x4 *>(p + 4 * q);
@@ -258,9 +311,18 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
 
     auto macro_steps = [&](int tau_begin, int tau_end, auto slow_tag) __attribute__((always_inline)) {
         constexpr bool SLOW = decltype(slow_tag)::value;
+        // Steady state (tau >= G, so the entering column jt = tau + 1 + (C-1) G - w is >= 1: G C >= 2w + 1): the top lane's fetch
+        // offset advances by one frame per macro-step, clamped at column m; the other lanes stay out of range.
+        uint32_t yo_cur = kNoFrame, yo_cap = kNoFrame, yo_step = 0u;
+        if (!SLOW && gl == G - 1) {
+            yo_cap = b_off + (uint32_t)(m - 1) * FB;
+            yo_cur = min(b_off + (uint32_t)(tau_begin + (C - 1) * G - w) * FB, yo_cap);
+            yo_step = FB;
+        }
         for (int tau0 = tau_begin; tau0 < tau_end; tau0 += U) {
             apd_f32x4 fill_regs[NFILL];
             fill_load(tau0 + U + 1, fill_regs);                  // rows of the NEXT block, stored at this block's end
+            const float *const xrows = &xring[((tau0 + 1 - gl) & (R - 1)) * RS];   // rows tau0 + 1 - gl ... + U - 1, contiguous
 #pragma unroll
             for (int q = 0; q < U; ++q) {
                 const int tau = tau0 + q;
@@ -270,10 +332,15 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                 // column frame entering the group at tau + 1: fetched by the top lane straight into the dead slot
                 // (other lanes' offsets are out of range: no memory access, and the DPP below overwrites them)
                 {
-                    const int jt = tau + 1 + (C - 1) * G - w;
-                    const uint32_t yo = b_off + (uint32_t)((jt >= 1) ? (min(jt, m) - 1) : (HYBRID ? m : m + 1)) * FB;
-                    if (!(APD_ABLATE & 8)) load_frame<DN>(yf[e], rsrc, gl == G - 1 ? yo : kNoFrame);
-                    if (!HYBRID) read_row(xs[xb], tau + 1 - gl);  // next row frame from the wave's LDS ring
+                    if (SLOW) {
+                        const int jt = tau + 1 + (C - 1) * G - w;
+                        const uint32_t yo = b_off + (uint32_t)((jt >= 1) ? (min(jt, m) - 1) : (HYBRID ? m : m + 1)) * FB;
+                        if (!(APD_ABLATE & 8)) load_frame<DN>(yf[e], rsrc, gl == G - 1 ? yo : kNoFrame);
+                    } else {
+                        if (!(APD_ABLATE & 8)) load_frame<DN>(yf[e], rsrc, yo_cur);
+                        yo_cur = min(yo_cur + yo_step, yo_cap);
+                    }
+                    if (!HYBRID) read_row_at(xs[xb], xrows + q * RS);   // next row frame from the wave's LDS ring
                 }
                 // the C local distances of this row
                 float d[C];
@@ -285,8 +352,7 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                     // of the per-cell condition (never misses a cell; on a hit the exact per-cell test below decides).
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
-                        float sc;
-                        d[c] = frame_sq_expanded<D>(xs[xa], yf[(r + c) % S], sc);
+                        d[c] = frame_sq_expanded_pre<D>(xs[xa], yf[(r + c) % S]);
                     }
                     float dmin = d[0];
 #pragma unroll
@@ -294,16 +360,19 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                     if (C % 2 == 0) dmin = __builtin_fminf(dmin, d[C - 1]);
                     const bool any = (APD_ABLATE & 128) ? false : dmin < (xs[xa][D] + nmax_b) * tau_thr;
                     if (__builtin_expect(__ballot(any) != 0ull, 0)) {   // rare: placed out of the hot instruction stream
+                        float nx = xs[xa][D];
+                        asm volatile("" : "+v"(nx));              // a norm sum of its own: reusing the hot path's would keep nine of them
+                                                                 // alive across the branch and turn their v_fmac into 3-operand v_fma
 #pragma unroll
                         for (int c = 0; c < C; ++c) {
-                            const float sc = xs[xa][D] + yf[(r + c) % S][D];
-                            const float ex = frame_sq_exact<D>(xs[xa], yf[(r + c) % S]);
+                            const float sc = nx + yf[(r + c) % S][D];
+                            const float ex = frame_sq_exact_pre<D>(xs[xa], yf[(r + c) % S]);
                             d[c] = (d[c] < sc * tau_thr) ? ex : d[c];
                         }
                     }
 #pragma unroll
                     for (int c = 0; c < C; ++c) d[c] = (APD_ABLATE & 1) ? d[c] : __builtin_amdgcn_sqrtf(d[c]);
-                    read_row(xs[0], tau + 1 - gl);                // the row frame is dead now: fetch the next one under the DP rows
+                    read_row_at(xs[0], xrows + q * RS);           // the row frame is dead now: fetch the next one under the DP rows
                 } else {
 #pragma unroll
                     for (int c = 0; c < C; ++c)
@@ -315,8 +384,13 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                     }
                 }
                 // the two DP rows
-                float left1 = group_from_lower<G>(prev1[C - 1], APD_INF, gl);
-                float left2 = group_from_lower<G>(prev2[C - 1], APD_INF, gl);
+                // Exchanges across lanes wrap around the group (rotations: no +INF fill to materialise).  What the edge lanes
+                // receive is either +INF already or never looked at: lane 0's DELETE/INSERT neighbour comes from offset
+                // G*C - 1 >= 2w, outside DP1's band and therefore +INF (guarded nodes sit on their +INF MATCH predecessor), and
+                // its DP2 node (u = 0) is guarded itself; lane G-1's last node is guarded in DP1, and in DP2 either guarded
+                // (G*C - 1 > 2w) or handed lane 0's guarded u = 0 node, +INF.
+                float left1 = group_from_lower_wrap<G>(prev1[C - 1], APD_INF, gl);
+                float left2 = group_from_lower_wrap<G>(prev2[C - 1], APD_INF, gl);
                 float upr1 = APD_INF, upr2 = APD_INF;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
@@ -329,8 +403,8 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                     prev1[c] = r1; prev2[c] = r2;
                     left1 = r1; left2 = r2;
                     if (c == 0) {
-                        upr1 = group_from_upper<G>(r1, APD_INF, gl);
-                        upr2 = group_from_upper<G>(r2, APD_INF, gl);
+                        upr1 = group_from_upper_wrap<G>(r1, APD_INF, gl);
+                        upr2 = group_from_upper_wrap<G>(r2, APD_INF, gl);
                     }
                 }
                 if (SLOW) {
