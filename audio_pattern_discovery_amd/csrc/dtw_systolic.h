@@ -233,6 +233,11 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     }
 #pragma unroll
     for (int k = 0; k < DN; ++k) yf[C][k] = 0.0f;
+    if (HYBRID && !(APD_ABLATE & 8)) {                           // hybrid form: columns are fetched one macro-step ahead (fetch_column)
+        const int jt = 1 + (C - 1) * G - w;
+        const uint32_t yo = b_off + (uint32_t)((jt >= 1) ? (min(jt, m) - 1) : m) * FB;
+        load_frame<DN>(yf[C], rsrc, gl == G - 1 ? yo : kNoFrame);
+    }
     // ring prologue: rows -(G-1)..0 are -INF, rows 1..U come from memory
     constexpr int NFILL = (U + FPF - 1) / FPF;
     const int fill_f = lane / LPF, fill_q = lane % LPF;          // this lane's frame and 16-byte piece inside a fill
@@ -309,16 +314,37 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
 #pragma unroll
     for (int c = 0; c < C; ++c) dn[c] = (PIPE && !HYBRID && c < C - 1) ? frame_dist<D, DN>(xs[0], yf[c]) : 0.0f;
 
+    // advance the column window: every column moves one lane down (q: position inside the unrolled block)
+    auto advance_window = [&](int q) __attribute__((always_inline)) {
+        const int r = q % S, e = (r + C) % S;
+#pragma unroll
+        for (int k = 0; k < (HYBRID ? DN : D); ++k) {
+            if (APD_ABLATE & 4) { yf[e][k] = yf[(r + 1) % S][k] + yf[e][k]; continue; }
+            yf[e][k] = group_from_upper<G>(yf[(r + 1) % S][k], yf[e][k], gl);
+        }
+    };
     auto macro_steps = [&](int tau_begin, int tau_end, auto slow_tag) __attribute__((always_inline)) {
         constexpr bool SLOW = decltype(slow_tag)::value;
         // Steady state (tau >= G, so the entering column jt = tau + 1 + (C-1) G - w is >= 1: G C >= 2w + 1): the top lane's fetch
         // offset advances by one frame per macro-step, clamped at column m; the other lanes stay out of range.
         uint32_t yo_cur = kNoFrame, yo_cap = kNoFrame, yo_step = 0u;
-        if (!SLOW && gl == G - 1) {
+        if (!SLOW && gl == G - 1) {                              // (hybrid form: fetched one macro-step ahead, see below)
             yo_cap = b_off + (uint32_t)(m - 1) * FB;
-            yo_cur = min(b_off + (uint32_t)(tau_begin + (C - 1) * G - w) * FB, yo_cap);
+            yo_cur = min(b_off + (uint32_t)(tau_begin + (HYBRID ? 1 : 0) + (C - 1) * G - w) * FB, yo_cap);
             yo_step = FB;
         }
+        // the column entering the group at step t + 1, fetched by the top lane
+        auto fetch_column = [&](float (&dst)[DN], int t) __attribute__((always_inline)) {
+            if (APD_ABLATE & 8) return;
+            if (SLOW) {
+                const int jt = t + 1 + (C - 1) * G - w;
+                const uint32_t yo = b_off + (uint32_t)((jt >= 1) ? (min(jt, m) - 1) : (HYBRID ? m : m + 1)) * FB;
+                load_frame<DN>(dst, rsrc, gl == G - 1 ? yo : kNoFrame);
+            } else {
+                load_frame<DN>(dst, rsrc, yo_cur);
+                yo_cur = min(yo_cur + yo_step, yo_cap);
+            }
+        };
         for (int tau0 = tau_begin; tau0 < tau_end; tau0 += U) {
             apd_f32x4 fill_regs[NFILL];
             fill_load(tau0 + U + 1, fill_regs);                  // rows of the NEXT block, stored at this block's end
@@ -331,16 +357,10 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                 const int e = (r + C) % S;         // slot of the column entering at tau + 1 (dead during this step)
                 // column frame entering the group at tau + 1: fetched by the top lane straight into the dead slot
                 // (other lanes' offsets are out of range: no memory access, and the DPP below overwrites them)
-                {
-                    if (SLOW) {
-                        const int jt = tau + 1 + (C - 1) * G - w;
-                        const uint32_t yo = b_off + (uint32_t)((jt >= 1) ? (min(jt, m) - 1) : (HYBRID ? m : m + 1)) * FB;
-                        if (!(APD_ABLATE & 8)) load_frame<DN>(yf[e], rsrc, gl == G - 1 ? yo : kNoFrame);
-                    } else {
-                        if (!(APD_ABLATE & 8)) load_frame<DN>(yf[e], rsrc, yo_cur);
-                        yo_cur = min(yo_cur + yo_step, yo_cap);
-                    }
-                    if (!HYBRID) read_row_at(xs[xb], xrows + q * RS);   // next row frame from the wave's LDS ring
+                // (hybrid form: the window moves in the middle of the step, so the frame is fetched a step ahead, see fetch_column)
+                if (!HYBRID) {
+                    fetch_column(yf[e], tau);
+                    read_row_at(xs[xb], xrows + q * RS);         // next row frame from the wave's LDS ring
                 }
                 // the C local distances of this row
                 float d[C];
@@ -359,6 +379,9 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                     for (int c = 1; c + 1 < C; c += 2) dmin = __builtin_fminf(__builtin_fminf(dmin, d[c]), d[c + 1]);
                     if (C % 2 == 0) dmin = __builtin_fminf(dmin, d[C - 1]);
                     const bool any = (APD_ABLATE & 128) ? false : dmin < (xs[xa][D] + nmax_b) * tau_thr;
+                    // The window moves here, between the test and the branch on it: the slot it writes is dead, nothing below
+                    // reads the one it vacates before the next step, and the 14 moves cover the latency of compare -> branch.
+                    advance_window(q);
                     if (__builtin_expect(__ballot(any) != 0ull, 0)) {   // rare: placed out of the hot instruction stream
                         float nx = xs[xa][D];
                         asm volatile("" : "+v"(nx));              // a norm sum of its own: reusing the hot path's would keep nine of them
@@ -370,6 +393,9 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                             d[c] = (d[c] < sc * tau_thr) ? ex : d[c];
                         }
                     }
+                    // slot r (this step's first column) is dead from here on, and it is the slot the NEXT step's window move fills:
+                    // fetch that step's entering column now, a whole macro-step before it is needed
+                    fetch_column(yf[r], tau + 1);
 #pragma unroll
                     for (int c = 0; c < C; ++c) d[c] = (APD_ABLATE & 1) ? d[c] : __builtin_amdgcn_sqrtf(d[c]);
                     read_row_at(xs[0], xrows + q * RS);           // the row frame is dead now: fetch the next one under the DP rows
@@ -417,12 +443,7 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                         for (int c = 0; c < C; ++c) if (c == cstar) { res1 = prev1[c]; res2 = prev2[c]; }
                     }
                 }
-                // advance the column window: every column moves one lane down
-#pragma unroll
-                for (int k = 0; k < (HYBRID ? DN : D); ++k) {
-                    if (APD_ABLATE & 4) { yf[e][k] = yf[(r + 1) % S][k] + yf[e][k]; continue; }
-                    yf[e][k] = group_from_upper<G>(yf[(r + 1) % S][k], yf[e][k], gl);
-                }
+                if (!HYBRID) advance_window(q);
             }
             fill_store(tau0 + U + 1, fill_regs);
             asm volatile("" ::: "memory");                       // rows written by other lanes are read in the next block: no

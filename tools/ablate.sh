@@ -3,7 +3,7 @@
 cd /root/repo/audio_pattern_discovery_amd/csrc
 mkdir -p /root/repo/build/ablate /tmp/t
 for a in "$@"; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -DAPD_ABLATE=$a -c dtw_sys_d13.hip -o /tmp/t/abl_$a.o &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp -DAPD_ABLATE=$a -c dtw_sys_d13.hip -o /tmp/t/abl_$a.o &
 done
 wait
 for a in "$@"; do
