@@ -16,6 +16,13 @@
              "s_mov_b64 %11, exec\n v_cmpx_neq_f32 vcc, %5, %7\n v_min3_f32 %6, %5, %7, %6\n s_mov_b64 exec, %11\n v_add_f32 %5, %6, %8\n"
 #define SEL3 "v_cmpx_neq_f32 vcc, %0, %2\n v_min3_f32 %1, %0, %2, %1\n s_mov_b64 exec, %10\n v_add_f32 %0, %1, %3\n s_nop 0\n" \
              "v_cmpx_neq_f32 vcc, %5, %7\n v_min3_f32 %6, %5, %7, %6\n s_mov_b64 exec, %10\n v_add_f32 %5, %6, %8\n s_nop 0\n"
+// mode 4: the tie rule in integer arithmetic, no lane mask: x = (l ^ u) - 1 is negative iff l == u (non-negative floats);
+//         k = min_i32(x, 0) is all ones iff tie; r = min(min(l, u) | k, m) -- the OR makes a NaN, which v_min drops; r += d
+#define SEL4 "v_xad_u32 %4, %0, %2, -1\n v_min_f32 %0, %0, %2\n v_min_i32 %4, %4, 0\n v_or_b32 %0, %0, %4\n v_min_f32 %0, %0, %1\n v_add_f32 %0, %0, %3\n" \
+             "v_xad_u32 %9, %5, %7, -1\n v_min_f32 %5, %5, %7\n v_min_i32 %9, %9, 0\n v_or_b32 %5, %5, %9\n v_min_f32 %5, %5, %6\n v_add_f32 %5, %5, %8\n"
+// mode 5: the same with a guard value folded into the integer minimum (k = min3_i32(x, 0, g))
+#define SEL5 "v_xad_u32 %4, %0, %2, -1\n v_min_f32 %0, %0, %2\n v_min3_i32 %4, %4, 0, %1\n v_or_b32 %0, %0, %4\n v_min_f32 %0, %0, %1\n v_add_f32 %0, %0, %3\n" \
+             "v_xad_u32 %9, %5, %7, -1\n v_min_f32 %5, %5, %7\n v_min3_i32 %9, %9, 0, %6\n v_or_b32 %5, %5, %9\n v_min_f32 %5, %5, %6\n v_add_f32 %5, %5, %8\n"
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float *out, int iters)
 {
@@ -27,6 +34,8 @@ __global__ __launch_bounds__(256) void k(float *out, int iters)
         if (MODE == 0) asm volatile(REP8(SEL0) : "+v"(l1), "+v"(m1), "+v"(u1), "+v"(d1), "+v"(t1), "+v"(l2), "+v"(m2), "+v"(u2), "+v"(d2), "+v"(t2) : "s"(ex) : "vcc");
         if (MODE == 1) asm volatile(REP8(SEL1) : "+v"(l1), "+v"(m1), "+v"(u1), "+v"(d1), "+v"(t1), "+v"(l2), "+v"(m2), "+v"(u2), "+v"(d2), "+v"(t2) : "s"(ex) : "vcc");
         if (MODE == 2) asm volatile(REP8(SEL2) : "+v"(l1), "+v"(m1), "+v"(u1), "+v"(d1), "+v"(t1), "+v"(l2), "+v"(m2), "+v"(u2), "+v"(d2), "+v"(t2), "+s"(tmp) : "s"(ex) : "vcc");
+        if (MODE == 4) asm volatile(REP8(SEL4) : "+v"(l1), "+v"(m1), "+v"(u1), "+v"(d1), "+v"(t1), "+v"(l2), "+v"(m2), "+v"(u2), "+v"(d2), "+v"(t2) : "s"(ex) : "vcc");
+        if (MODE == 5) asm volatile(REP8(SEL5) : "+v"(l1), "+v"(m1), "+v"(u1), "+v"(d1), "+v"(t1), "+v"(l2), "+v"(m2), "+v"(u2), "+v"(d2), "+v"(t2) : "s"(ex) : "vcc");
         if (MODE == 3) asm volatile(REP8(SEL3) : "+v"(l1), "+v"(m1), "+v"(u1), "+v"(d1), "+v"(t1), "+v"(l2), "+v"(m2), "+v"(u2), "+v"(d2), "+v"(t2) : "s"(ex) : "vcc");
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = l1 + m1 + u1 + t1 + l2 + m2 + u2 + t2 + (float)tmp;
@@ -52,6 +61,8 @@ int main()
         printf("  cmpx_neq + masked min3 + s_mov + add   %.1f\n", run<1>(d, w, 20000));
         printf("  ... with exec saved in every block     %.1f\n", run<2>(d, w, 20000));
         printf("  ... mode 1 + s_nop 0                   %.1f\n", run<3>(d, w, 20000));
+        printf("  integer form: xad, min, min_i32, or, min, add  %.1f\n", run<4>(d, w, 20000));
+        printf("  integer form with a guard (min3_i32)   %.1f\n", run<5>(d, w, 20000));
     }
     return 0;
 }
