@@ -393,8 +393,11 @@ static hipError_t launch_align_chunk(const AlignLaunch &L, int geom_key, hipStre
     const bool unit = (b.ins == 1.0f) && (b.del == 1.0f) && (b.mat == 1.0f);   // the systolic kernel's UNIFORM_PEN path: no weighting at all
     bool done = false;
     AlignLaunch LL = L;
-    static const int hybrid_min_dim = std::getenv("APD_HYBRID_MIN_DIM") ? std::atoi(std::getenv("APD_HYBRID_MIN_DIM")) : 10;   // tuning aid
-    if ((int)LL.dim < hybrid_min_dim) LL.hybrid = 0;   // the norm expansion saves D - 4 vector ops per cell: not worth its branch below D = 10
+    // The norm expansion trades D - 1 vector ops per cell (systolic kernel, pre-scaled rows; D - 4 in the strip kernels) for a
+    // branch per macro-step: measured worth it from D = 8 in the systolic kernel (cfg 4: -2.6 %), from D = 10 elsewhere.
+    static const int hybrid_min_env = std::getenv("APD_HYBRID_MIN_DIM") ? std::atoi(std::getenv("APD_HYBRID_MIN_DIM")) : 0;   // tuning aid
+    const int hybrid_min_dim = hybrid_min_env ? hybrid_min_env : (geom_key >= 100 && geom_key < 10000 ? 8 : 10);
+    if ((int)LL.dim < hybrid_min_dim) LL.hybrid = 0;
     if (geom_key >= 20000) {
         const bool banded = geom_key >= 30000;
         const int nw = (geom_key % 10000) / 100, cw = geom_key % 100;

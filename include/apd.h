@@ -92,7 +92,7 @@ float apd_last_kernel_ms(apd_context *ctx);
 /* Tuning knob for experiments: 0 = pick automatically.  See DESIGN.md "Kernel variants". */
 int apd_set_variant(apd_context *ctx, int variant);
 /* Local-distance form of the fast kernels with UNIT penalties (1.0, 1.0, 1.0 -- the shipped Discovery.toml).
- * mode 0: sqrt(sum (x_k-y_k)^2) as an fma chain, ~2e-7 relative of the reference.  mode 1 (default, D >= 10):
+ * mode 0: sqrt(sum (x_k-y_k)^2) as an fma chain, ~2e-7 relative of the reference.  mode 1 (default, D >= 8 in the band kernel, D >= 10 in the strip kernels):
  * |x|^2 + |y|^2 - 2 x.y from precomputed frame norms, recomputed in the difference form wherever the result is below
  * tau * (|x|^2 + |y|^2) (cancellation region; tau <= 0 keeps the current value, default 1/64): 9 fewer vector ops
  * per cell, ~3e-7 relative measured (tolerance asked: 1e-4); exact copies score exactly 0 in both.
