@@ -94,8 +94,11 @@ __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
 #pragma unroll
         for (int f = 0; f < NFILL; ++f) {
             const int fi = f * FPF + fill_f;
-            if ((fill_f < FPF) & (fi < U))
-                *reinterpret_cast<apd_f32x4 *>(&xring[((first_row + fi) & (R - 1)) * DP + 4 * fill_q]) = regs[f];
+            if ((fill_f < FPF) & (fi < U)) {
+                apd_f32x4 v = regs[f];
+                if (HYBRID) prescale_row_piece<D>(v, fill_q);      // -2 x, norm slot kept: see frame_sq_expanded_pre
+                *reinterpret_cast<apd_f32x4 *>(&xring[((first_row + fi) & (R - 1)) * DP + 4 * fill_q]) = v;
+            }
         }
     };
     auto read_row = [&](float (&dst)[DN], int row) __attribute__((always_inline)) {
@@ -144,20 +147,19 @@ __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
                 if (HYBRID) {
                     // one superset test per macro-step instead of one per cell (see dtw_systolic.h)
 #pragma unroll
-                    for (int c = 0; c < CW; ++c) {
-                        float sc;
-                        d[c] = frame_sq_expanded<D>(xs, yf[c], sc);
-                    }
+                    for (int c = 0; c < CW; ++c) d[c] = frame_sq_expanded_pre<D>(xs, yf[c]);
                     float dmin = d[0];
 #pragma unroll
                     for (int c = 1; c + 1 < CW; c += 2) dmin = __builtin_fminf(__builtin_fminf(dmin, d[c]), d[c + 1]);
                     if (CW % 2 == 0) dmin = __builtin_fminf(dmin, d[CW - 1]);
                     const bool any = dmin < (xs[D] + nmax_ab) * tau_thr;
                     if (__builtin_expect(__ballot(any) != 0ull, 0)) {   // rare: placed out of the hot instruction stream
+                        float nx = xs[D];
+                        asm volatile("" : "+v"(nx));              // see dtw_systolic.h: keeps the hot path's norm sums out of this block
 #pragma unroll
                         for (int c = 0; c < CW; ++c) {
-                            const float sc = xs[D] + yf[c][D];
-                            const float ex = frame_sq_exact<D>(xs, yf[c]);
+                            const float sc = nx + yf[c][D];
+                            const float ex = frame_sq_exact_pre<D>(xs, yf[c]);
                             d[c] = (d[c] < sc * tau_thr) ? ex : d[c];
                         }
                     }
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
 #pragma unroll
                     for (int c = 0; c < CW; ++c) d[c] = GENERAL_PEN ? frame_dist_strict<D, DN>(xs, yf[c]) : frame_dist<D, DN>(xs, yf[c]);
                 }
-                if (!GENERAL_PEN) weight_distances<CW>(d, pen);
+                if (!GENERAL_PEN && !HYBRID) weight_distances<CW>(d, pen);   // the hybrid form is only launched with unit penalties
                 read_row(xs, tau + 1 - gl);                       // the row frame is dead: fetch the next one under the DP row
                 // DELETE input of the first column: last cell of the lane below (row i); lane 0 of a pair takes the boundary
                 // column of the previous pass (row tau; rows past n-1 are never used), column 0 does not exist in pass 0
@@ -260,7 +262,7 @@ static hipError_t launch_full_c(const AlignLaunch &L, hipStream_t stream)
     const size_t lds_bytes = ((size_t)R * DP + (size_t)PPW * (BANDED ? 2 : 1) * (L.n_max + 4) + 16) * sizeof(float);
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;      // the dispatcher keeps such tiles off this kernel
     const dim3 grid(L.n_tiles * (kSlotsPerTile / PPW)), block(64);
-    const bool hybrid = L.hybrid && D >= 10;
+    const bool hybrid = L.hybrid && D >= 10 && L.band.mat == 1.0f;   // (equal penalties here: all three are 1)
     const void *fn = hybrid ? reinterpret_cast<const void *>(dtw_full_matrix<D, CW, G, true, BANDED>)
                             : reinterpret_cast<const void *>(dtw_full_matrix<D, CW, G, false, BANDED>);
     if (lds_bytes > 64 * 1024) {

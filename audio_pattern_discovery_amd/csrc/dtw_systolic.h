@@ -90,17 +90,8 @@ __device__ __forceinline__ float frame_dist_strict(const float (&x)[DN], const f
     return __builtin_sqrtf(acc);                                  // correctly rounded (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt)
 }
 
-// Squared distance by norm expansion: x[D], y[D] hold the squared norms.  13 fma + 2 instead of 26 (D = 13).
-template <int D>
-__device__ __forceinline__ float frame_sq_expanded(const float (&x)[D + 1], const float (&y)[D + 1], float &s_out)
-{
-    float dot = x[0] * y[0];
-#pragma unroll
-    for (int k = 1; k < D; ++k) dot = __builtin_fmaf(x[k], y[k], dot);
-    s_out = x[D] + y[D];
-    return __builtin_fmaf(-2.0f, dot, s_out);
-}
-// The same with the row frame pre-scaled: xm[k] = -2 x[k] (done once per row when the wave stages it in LDS), xm[D] = |x|^2.
+// Squared distance by norm expansion, |x|^2 + |y|^2 - 2 x.y: x[D], y[D] hold the squared norms, and the row frame comes
+// pre-scaled: xm[k] = -2 x[k] (done once per row when the wave stages it in LDS), xm[D] = |x|^2.
 // |x|^2 + |y|^2 + sum xm_k y_k: one add and D v_fmac -- the multiply that opens the dot product and the closing fma(-2, ., .) are gone.
 template <int D>
 __device__ __forceinline__ float frame_sq_expanded_pre(const float (&xm)[D + 1], const float (&y)[D + 1])
@@ -109,6 +100,16 @@ __device__ __forceinline__ float frame_sq_expanded_pre(const float (&xm)[D + 1],
 #pragma unroll
     for (int k = 0; k < D; ++k) acc = __builtin_fmaf(xm[k], y[k], acc);
     return acc;
+}
+// One 16-byte piece (components 4 piece .. 4 piece + 3) of a row frame on its way into the LDS ring: times -2, the norm kept.
+template <int D>
+__device__ __forceinline__ void prescale_row_piece(apd_f32x4 &v, int piece)
+{
+    const bool np = piece == D / 4;                              // the piece that holds the norm
+    v.x = (np && D % 4 == 0) ? v.x : -2.0f * v.x;
+    v.y = (np && D % 4 == 1) ? v.y : -2.0f * v.y;
+    v.z = (np && D % 4 == 2) ? v.z : -2.0f * v.z;
+    v.w = (np && D % 4 == 3) ? v.w : -2.0f * v.w;
 }
 // Difference form from the pre-scaled row frame: fma(-0.5, xm_k, -y_k) is x_k - y_k with its one rounding (the scaling is exact).
 template <int D>
@@ -123,19 +124,6 @@ __device__ __forceinline__ float frame_sq_exact_pre(const float (&xm)[D + 1], co
     }
     return acc;
 }
-template <int D>
-__device__ __forceinline__ float frame_sq_exact(const float (&x)[D + 1], const float (&y)[D + 1])
-{
-    float t = x[0] - y[0];
-    float acc = t * t;
-#pragma unroll
-    for (int k = 1; k < D; ++k) {
-        t = x[k] - y[k];
-        acc = __builtin_fmaf(t, t, acc);
-    }
-    return acc;
-}
-
 template <int D, int C, int G, bool UNIFORM_PEN, bool HYBRID>
 __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
 {
@@ -256,13 +244,7 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
             const int fi = f * FPF + fill_f;
             if ((fill_f < FPF) & (fi < U)) {
                 apd_f32x4 v = regs[f];
-                if (HYBRID) {                                    // stage -2 x (the norm slot stays): see frame_sq_expanded_pre
-                    const bool np = fill_q == D / 4;             // the piece that holds the norm
-                    v.x = (np && D % 4 == 0) ? v.x : -2.0f * v.x;
-                    v.y = (np && D % 4 == 1) ? v.y : -2.0f * v.y;
-                    v.z = (np && D % 4 == 2) ? v.z : -2.0f * v.z;
-                    v.w = (np && D % 4 == 3) ? v.w : -2.0f * v.w;
-                }
+                if (HYBRID) prescale_row_piece<D>(v, fill_q);    // stage -2 x (the norm slot stays): see frame_sq_expanded_pre
                 const int slot = (first_row + fi) & (R - 1);
                 *reinterpret_cast<apd_f32x4 *>(&xring[slot * RS + 4 * fill_q]) = v;
                 if (slot < U) *reinterpret_cast<apd_f32x4 *>(&xring[(slot + R) * RS + 4 * fill_q]) = v;   // the copy behind the ring

@@ -90,8 +90,11 @@ __global__ __launch_bounds__(64 * NW) void dtw_fused_wide(const AlignLaunch L)
 #pragma unroll
         for (int f = 0; f < NFILL; ++f) {
             const int fi = f * FPF + fill_f;
-            if ((wv == 0) & (fill_f < FPF) & (fi < U))
-                *reinterpret_cast<apd_f32x4 *>(&xring[((first_row + fi) & (R - 1)) * DP + 4 * fill_q]) = regs[f];
+            if ((wv == 0) & (fill_f < FPF) & (fi < U)) {
+                apd_f32x4 v = regs[f];
+                if (HYBRID) prescale_row_piece<D>(v, fill_q);      // -2 x, norm slot kept: see frame_sq_expanded_pre
+                *reinterpret_cast<apd_f32x4 *>(&xring[((first_row + fi) & (R - 1)) * DP + 4 * fill_q]) = v;
+            }
         }
     };
     for (int e = gl; e < G * DP; e += G)
@@ -156,20 +159,19 @@ __global__ __launch_bounds__(64 * NW) void dtw_fused_wide(const AlignLaunch L)
                 if (HYBRID) {
                     // one superset test per macro-step instead of one per cell (see dtw_systolic.h)
 #pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        float sc;
-                        d[c] = frame_sq_expanded<D>(xs, yf[(r + c) % S], sc);
-                    }
+                    for (int c = 0; c < C; ++c) d[c] = frame_sq_expanded_pre<D>(xs, yf[(r + c) % S]);
                     float dmin = d[0];
 #pragma unroll
                     for (int c = 1; c + 1 < C; c += 2) dmin = __builtin_fminf(__builtin_fminf(dmin, d[c]), d[c + 1]);
                     if (C % 2 == 0) dmin = __builtin_fminf(dmin, d[C - 1]);
                     const bool any = dmin < (xs[D] + nmax_ab) * tau_thr;
                     if (__builtin_expect(__ballot(any) != 0ull, 0)) {   // rare: placed out of the hot instruction stream
+                        float nx = xs[D];
+                        asm volatile("" : "+v"(nx));              // see dtw_systolic.h: keeps the hot path's norm sums out of this block
 #pragma unroll
                         for (int c = 0; c < C; ++c) {
-                            const float sc = xs[D] + yf[(r + c) % S][D];
-                            const float ex = frame_sq_exact<D>(xs, yf[(r + c) % S]);
+                            const float sc = nx + yf[(r + c) % S][D];
+                            const float ex = frame_sq_exact_pre<D>(xs, yf[(r + c) % S]);
                             d[c] = (d[c] < sc * tau_thr) ? ex : d[c];
                         }
                     }
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(64 * NW) void dtw_fused_wide(const AlignLaunch L)
 #pragma unroll
                     for (int c = 0; c < C; ++c) d[c] = frame_dist<D, DN>(xs, yf[(r + c) % S]);
                 }
-                weight_distances<C>(d, pen);
+                if (!HYBRID) weight_distances<C>(d, pen);          // the hybrid form is only launched with unit penalties
                 // first cell, then the seam exchange of the "up" neighbour
                 float left1 = from_lower_lane(prev1[C - 1], lf1);
                 float left2 = from_lower_lane(prev2[C - 1], lf2);
@@ -245,7 +247,7 @@ static hipError_t launch_wide_cn(const AlignLaunch &L, hipStream_t stream)
     constexpr int G = 64 * NW, DP = (D + 1 + 3) & ~3, R = (G <= 256) ? 512 : 1024;
     const size_t lds_bytes = ((size_t)R * DP + (NW + 1) * DP + 4 * (NW + 1)) * sizeof(float);
     const dim3 grid(L.n_tiles * kSlotsPerTile), block(G);
-    const bool hybrid = L.hybrid && D >= 10;
+    const bool hybrid = L.hybrid && D >= 10 && L.band.mat == 1.0f;   // (equal penalties here: all three are 1)
     const void *fn = hybrid ? reinterpret_cast<const void *>(dtw_fused_wide<D, C, NW, true>) : reinterpret_cast<const void *>(dtw_fused_wide<D, C, NW, false>);
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
