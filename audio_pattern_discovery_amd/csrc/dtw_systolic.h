@@ -20,6 +20,7 @@
 // Timing-only ablations for kernel tuning (results become wrong): build one unit with -DAPD_ABLATE=<bits>.
 //   1 no sqrt   2 no DP rows   4 no frame shifts   8 no edge fetches   16 no band guards   32 software-pipelined distances (valid results)
 //   64 select = min3 + d (no tie rule, no guards: what a deferred tie check could save at most)   128 no hybrid threshold test
+//   512 G = 32 without the one-instruction wave shift + masked column fetch (valid results)
 #ifndef APD_ABLATE
 #define APD_ABLATE 0
 #endif
@@ -202,6 +203,11 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     constexpr int S = C + 1;
     constexpr int U = (S % 2 == 0) ? S : 2 * S;
     static_assert(U == U_ROWS, "ring copy sized for another unroll");
+    // G = 32 (two DPP rows per group), hybrid form: a shift inside the group takes two DPP instructions per register (the rows
+    // that read across a row boundary, and the rows that end a group and must keep the fetched frame).  Instead the whole wave
+    // shifts by one lane with ONE instruction -- the two group-top lanes receive a frame of the neighbouring pair or keep a
+    // stale one -- and only those lanes then fetch their entering column, under EXEC, on top of it.
+    constexpr bool MASKED_FETCH = HYBRID && G == 32 && !(APD_ABLATE & 512);
     const int total_r = ((total + U - 1) / U) * U;
     const int a_end = min(((G + U - 1) / U) * U, total_r);
     const int b_end = min(max((min_rows / U) * U, a_end), total_r);
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     }
 #pragma unroll
     for (int k = 0; k < DN; ++k) yf[C][k] = 0.0f;
-    if (HYBRID && !(APD_ABLATE & 8)) {                           // hybrid form: columns are fetched one macro-step ahead (fetch_column)
+    if (HYBRID && !MASKED_FETCH && !(APD_ABLATE & 8)) {          // hybrid form: columns are fetched one macro-step ahead (fetch_column)
         const int jt = 1 + (C - 1) * G - w;
         const uint32_t yo = b_off + (uint32_t)((jt >= 1) ? (min(jt, m) - 1) : m) * FB;
         load_frame<DN>(yf[C], rsrc, gl == G - 1 ? yo : kNoFrame);
@@ -302,7 +308,8 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
 #pragma unroll
         for (int k = 0; k < (HYBRID ? DN : D); ++k) {
             if (APD_ABLATE & 4) { yf[e][k] = yf[(r + 1) % S][k] + yf[e][k]; continue; }
-            yf[e][k] = group_from_upper<G>(yf[(r + 1) % S][k], yf[e][k], gl);
+            yf[e][k] = MASKED_FETCH ? dpp_move<0x130>(yf[(r + 1) % S][k], yf[e][k])      // wave_shl:1, every row
+                                    : group_from_upper<G>(yf[(r + 1) % S][k], yf[e][k], gl);
         }
     };
     auto macro_steps = [&](int tau_begin, int tau_end, auto slow_tag) __attribute__((always_inline)) {
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
         uint32_t yo_cur = kNoFrame, yo_cap = kNoFrame, yo_step = 0u;
         if (!SLOW && gl == G - 1) {                              // (hybrid form: fetched one macro-step ahead, see below)
             yo_cap = b_off + (uint32_t)(m - 1) * FB;
-            yo_cur = min(b_off + (uint32_t)(tau_begin + (HYBRID ? 1 : 0) + (C - 1) * G - w) * FB, yo_cap);
+            yo_cur = min(b_off + (uint32_t)(tau_begin + ((HYBRID && !MASKED_FETCH) ? 1 : 0) + (C - 1) * G - w) * FB, yo_cap);
             yo_step = FB;
         }
         // the column entering the group at step t + 1, fetched by the top lane
@@ -364,6 +371,9 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                     // The window moves here, between the test and the branch on it: the slot it writes is dead, nothing below
                     // reads the one it vacates before the next step, and the 14 moves cover the latency of compare -> branch.
                     advance_window(q);
+                    if (MASKED_FETCH) {
+                        if (gl == G - 1) fetch_column(yf[e], tau);   // the column entering at tau + 1, on top of what the shift left there
+                    }
                     if (__builtin_expect(__ballot(any) != 0ull, 0)) {   // rare: placed out of the hot instruction stream
                         float nx = xs[xa][D];
                         asm volatile("" : "+v"(nx));              // a norm sum of its own: reusing the hot path's would keep nine of them
@@ -377,7 +387,7 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                     }
                     // slot r (this step's first column) is dead from here on, and it is the slot the NEXT step's window move fills:
                     // fetch that step's entering column now, a whole macro-step before it is needed
-                    fetch_column(yf[r], tau + 1);
+                    if (!MASKED_FETCH) fetch_column(yf[r], tau + 1);
 #pragma unroll
                     for (int c = 0; c < C; ++c) d[c] = (APD_ABLATE & 1) ? d[c] : __builtin_amdgcn_sqrtf(d[c]);
                     read_row_at(xs[0], xrows + q * RS);           // the row frame is dead now: fetch the next one under the DP rows
@@ -396,7 +406,9 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                 // receive is either +INF already or never looked at: lane 0's DELETE/INSERT neighbour comes from offset
                 // G*C - 1 >= 2w, outside DP1's band and therefore +INF (guarded nodes sit on their +INF MATCH predecessor), and
                 // its DP2 node (u = 0) is guarded itself; lane G-1's last node is guarded in DP1, and in DP2 either guarded
-                // (G*C - 1 > 2w) or handed lane 0's guarded u = 0 node, +INF.
+                // (G*C - 1 > 2w) or handed lane 0's guarded u = 0 node, +INF.  (G = 32: the rotation spans the wave; the nodes
+                // that wrap in come from the neighbouring group's edges, which meet the same conditions -- G*C >= 2w + 1 holds
+                // for every pair of the tile, and idle groups sweep a 1 x 1 dummy with w = 2.)
                 float left1 = group_from_lower_wrap<G>(prev1[C - 1], APD_INF, gl);
                 float left2 = group_from_lower_wrap<G>(prev2[C - 1], APD_INF, gl);
                 float upr1 = APD_INF, upr2 = APD_INF;
