@@ -177,7 +177,9 @@ int apd_align_all_sharded_async(apd_context *ctx, apd_comm *comm, const apd_batc
  * apd_unpack_tiles_async below.  apd_all_gather_async is the library's collective on its own: d_send (count floats) of
  * every rank, concatenated in rank order into d_recv (count * world floats), on the context's stream. */
 int apd_all_gather_async(apd_context *ctx, apd_comm *comm, const float *d_send, float *d_recv, uint64_t count);
-/* frames / offsets / out: host memory, as apd_batch_create + apd_align_all take them.  devices: HIP device ordinals. */
+/* frames / offsets / out: host memory, as apd_batch_create + apd_align_all take them.  devices: HIP device ordinals.
+ * Blocking; starts n_devices - 1 host threads of its own for the uploads and launches (joined before it returns) -- the
+ * counterpart of the reference's `alignment_workers` threads, one per GPU. */
 int apd_align_all_multi(const int *devices, uint32_t n_devices, const float *frames, const uint64_t *offsets, uint32_t n_seq,
                         uint32_t dim, const apd_align_config *cfg, float *out, uint32_t *ranks_seen);
 
