@@ -13,7 +13,13 @@
 //    dispatcher takes the generic kernel); D[0][0] = 0 (alignments.rs:109) is injected and the result cell
 //    (n-1, m-1) (alignments.rs:120) captured only in the first G and last G macro-steps ("slow" phases);
 //  * the static band edges (DP1 stops at u = 2w-1, DP2 spans u = 1..2w) are two per-lane scalar masks per offset
-//    OR-ed into the select (see select_node): no vector instruction.
+//    OR-ed into the select (see select_node): no vector instruction;
+//  * hybrid distance form (unit penalties): |x|^2 + |y|^2 - 2 x.y with the row frames pre-scaled by -2 when they are staged
+//    (one add + D fmac per cell), ONE superset threshold test per macro-step in front of a rarely taken recompute branch, the
+//    window moves issued between that test and its branch, the entering column fetched a macro-step ahead;
+//  * steady-state macro-steps carry no address arithmetic (running column offset, contiguous LDS row window) and the DP rows'
+//    edge exchanges are rotations (what wraps around is +INF or feeds a guarded node).
+// DESIGN.md section 4.1 has the instruction budget, the measurements and what was tried and dropped.
 #pragma once
 #include <type_traits>
 
