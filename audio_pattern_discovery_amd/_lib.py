@@ -197,8 +197,9 @@ class Context:
         check(lib().apd_set_variant(self.handle, int(v)))
 
     def set_distance_mode(self, mode, tau=0.0):
-        """0 / "exact": difference form; 1 / "hybrid": norm expansion with exact recomputation below tau."""
-        mode = {"exact": 0, "hybrid": 1}.get(mode, mode)
+        """0 / "exact": difference form; 1 / "hybrid": norm expansion with exact recomputation below tau;
+        2 / "strict": the reference's arithmetic operation for operation (bit-identical scores, ~2.5x slower)."""
+        mode = {"exact": 0, "hybrid": 1, "strict": 2}.get(mode, mode)
         check(lib().apd_set_distance_mode(self.handle, int(mode), float(tau)))
 
     def selftest(self):

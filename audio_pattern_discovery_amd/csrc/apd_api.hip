@@ -216,7 +216,7 @@ extern "C" int apd_set_variant(apd_context *ctx, int variant)
 
 extern "C" int apd_set_distance_mode(apd_context *ctx, int mode, float tau)
 {
-    if (!ctx || (mode != 0 && mode != 1) || !(tau >= 0.0f)) return APD_ERR_INVALID_ARG;
+    if (!ctx || mode < 0 || mode > 2 || !(tau >= 0.0f)) return APD_ERR_INVALID_ARG;
     ctx->distance_mode = mode;
     if (tau > 0.0f) ctx->tau = tau;
     return APD_OK;
@@ -464,7 +464,7 @@ static int check_lengths(const apd_batch *b)
 // from the lengths of its 32 sequences), one launch per group: a few long or unequal sequences do not force every pair
 // onto a wide kernel.  The plan (device tile list + classes) is cached in the batch.
 static int build_tile_plan(apd_context *ctx, const apd_batch *batch, const BandSpec &band, uint32_t rank, uint32_t world,
-                           bool fast_ok, bool uniform_pen, apd_batch::TilePlan &plan_out)
+                           bool fast_ok, bool uniform_pen, bool fast_shift, apd_batch::TilePlan &plan_out)
 {
     apd_batch::TilePlan plan;                                             // built locally, published only when complete
     std::vector<uint2> tiles;
@@ -483,7 +483,7 @@ static int build_tile_plan(apd_context *ctx, const apd_batch *batch, const BandS
         const uint32_t mx = std::max(hi[tiles[t].x], hi[tiles[t].y]), mn = std::min(lo[tiles[t].x], lo[tiles[t].y]);
         const uint32_t band_ub = band.use_explicit ? band.explicit_band : host_band_from_pct(band.pct, mx);
         const uint32_t w = std::max(std::min(band_ub, mx), mx - mn) + 2;   // >= w of every pair of the tile
-        int key = fast_ok ? pick_geometry_key(2 * w + 1, batch->dim, ctx->variant, uniform_pen) : 0;
+        int key = fast_ok ? pick_geometry_key(2 * w + 1, batch->dim, ctx->variant, uniform_pen, fast_shift) : 0;
         // the band binds nowhere in this tile (band >= longest - 3 for its longest sequence, hence for all) and the penalties
         // are equal: both ordered scores are one number, swept over column strips (dtw_full.h).  Not for very short columns,
         // where four pairs per wavefront in band form keep more lanes busy.
@@ -583,16 +583,22 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
     rc = batch_nonfinite(ctx, batch, &nonfinite);
     if (rc) return rc;
     const bool fast_ok = pens_ok && batch->frames_bytes != 0 && !nonfinite;
-    const bool uniform_pen = (band.ins == band.del) && (band.del == band.mat);
+    // strict mode: every tile takes the kernels built for unequal penalties -- literal comparison chain on distances computed
+    // operation for operation as numerics.rs:114-120 -- which are bit-identical to the CPU arithmetic for ANY penalties
+    const bool strict = ctx->distance_mode == 2;
+    const bool uniform_pen = (band.ins == band.del) && (band.del == band.mat) && !strict;
     char keybuf[160];
     uint32_t pct_bits;
     std::memcpy(&pct_bits, &band.pct, sizeof(pct_bits));
-    std::snprintf(keybuf, sizeof(keybuf), "%u/%u/%08x/%u/%d/%d/%d/%d", rank, world, pct_bits, band.explicit_band, band.use_explicit,
-                  ctx->variant, (int)fast_ok, (int)uniform_pen);   // everything the choice of kernels depends on
+    // the band kernel's hybrid form with unit penalties moves its column window with one DPP instruction per register at any
+    // group size (dtw_systolic.h, MASKED_FETCH): 8- and 32-lane groups cost no more than 16- and 64-lane ones there
+    const bool fast_shift = band.ins == 1.0f && band.del == 1.0f && band.mat == 1.0f && ctx->distance_mode == 1 && batch->dim >= 8;
+    std::snprintf(keybuf, sizeof(keybuf), "%u/%u/%08x/%u/%d/%d/%d/%d/%d", rank, world, pct_bits, band.explicit_band, band.use_explicit,
+                  ctx->variant, (int)fast_ok, (int)uniform_pen, (int)fast_shift);   // everything the choice of kernels depends on
     auto cached = batch->tile_cache.find(keybuf);
     if (cached == batch->tile_cache.end()) {
         apd_batch::TilePlan fresh;
-        rc = build_tile_plan(ctx, batch, band, rank, world, fast_ok, uniform_pen, fresh);
+        rc = build_tile_plan(ctx, batch, band, rank, world, fast_ok, uniform_pen, fast_shift, fresh);
         if (rc) return rc;
         cached = batch->tile_cache.emplace(keybuf, std::move(fresh)).first;
     }
@@ -604,7 +610,7 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
     L.d_frames = batch->d_frames; L.frames_bytes = batch->frames_bytes; L.d_seq_off = batch->d_seq_off; L.d_seq_nmax = batch->d_seq_nmax;
     L.n_seq = batch->n_seq; L.dim = batch->dim; L.dpad = batch->dpad; L.band = band; L.d_slab = d_slab;
     L.variant = ctx->variant;
-    L.hybrid = ctx->distance_mode; L.tau = ctx->tau;
+    L.hybrid = ctx->distance_mode == 1; L.strict = strict; L.tau = ctx->tau;
     if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     // Classes are independent (disjoint tiles, disjoint slab regions): with more than one, their launches are spread over
     // side streams forked from and joined back into the context's stream, so that a class of a few tiles does not hold the

@@ -42,6 +42,7 @@ struct AlignLaunch {
     uint32_t n_max;              // upper bound of the longer length over the pairs of this launch
     int variant;                 // 0 auto
     int hybrid;                  // 1: norm-expansion distances with exact recomputation below tau (see dtw_systolic.h)
+    int strict;                  // 1: the reference's arithmetic operation for operation, whatever the penalties (apd_set_distance_mode 2)
     float tau;
 };
 
@@ -57,7 +58,7 @@ constexpr int max_strip_columns(uint32_t d) { return d <= 10 ? 13 : (d <= 13 ? 1
 
 // geom_key = G * 100 + C of the systolic kernel, or 0 for the generic kernel (see pick_geometry_key)
 hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, std::string &err, int *status);
-int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen);
+int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen, bool fast_shift);
 // >= 20000: full-matrix kernel, 20000 + (pairs per wavefront) * 100 + CW, for pairs of at most `rows` x `cols` frames (0 if it does not apply)
 int pick_full_key(uint32_t cols, uint32_t rows, uint32_t dim, int variant);   // (>= 10000: wide kernel, 10000 + NW * 100 + C)
 double full_key_cost(uint32_t cols, uint32_t rows, uint32_t dim, int key);    // modelled cost of one pair on that geometry (+inf: does not apply)
@@ -118,7 +119,7 @@ struct apd_context {
     std::set<apd_comm *> comms;
     bool timed = false;
     int variant = 0;
-    int distance_mode = 1;            // 0 exact differences, 1 hybrid
+    int distance_mode = 1;            // 0 exact differences, 1 hybrid, 2 strict (bit-identical to the CPU arithmetic)
     float tau = 1.0f / 64.0f;
     std::string last_error;
     // reusable device workspaces

@@ -64,14 +64,14 @@ __device__ __forceinline__ float dpp_rotate(float v)
 template <int G>
 __device__ __forceinline__ float group_from_lower_wrap(float v, float fill, int gl)
 {
-    if (G == 16) return dpp_rotate<0x121>(v);
-    if (G == 64 || G == 32) return dpp_rotate<0x13C>(v);          // G = 32: the other group's edge node is as good as one's own
+    if (G == 16 || G == 8) return dpp_rotate<0x121>(v);          // G = 8, 32: the other group's edge node is as good as one's own
+    if (G == 64 || G == 32) return dpp_rotate<0x13C>(v);
     return group_from_lower<G>(v, fill, gl);
 }
 template <int G>
 __device__ __forceinline__ float group_from_upper_wrap(float v, float fill, int gl)
 {
-    if (G == 16) return dpp_rotate<0x12F>(v);
+    if (G == 16 || G == 8) return dpp_rotate<0x12F>(v);
     if (G == 64 || G == 32) return dpp_rotate<0x134>(v);
     return group_from_upper<G>(v, fill, gl);
 }

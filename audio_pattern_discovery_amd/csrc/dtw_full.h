@@ -285,7 +285,7 @@ bool launch_full(const AlignLaunch &L, bool banded, int ppw, int cw, hipStream_t
         if (ppw == 4) { *err = launch_full_c<D, CC, 16, false>(L, stream); return true; } } }
     APD_FCASE(3) APD_FCASE(5) APD_FCASE(7) APD_FCASE(9) APD_FCASE(11) APD_FCASE(13)
 #undef APD_FCASE
-    const bool general = !((L.band.ins == L.band.del) && (L.band.del == L.band.mat));   // unequal penalties: literal select, strict distances
+    const bool general = !((L.band.ins == L.band.del) && (L.band.del == L.band.mat)) || L.strict;   // unequal penalties (or strict mode): literal select, strict distances
 #define APD_BCASE(CC) if constexpr (CC <= max_cells_per_lane(D)) { if (cw == CC && banded) { \
         if (ppw == 1) { *err = general ? launch_full_general<D, CC, 64>(L, stream) : launch_full_c<D, CC, 64, true>(L, stream); return true; } \
         if (ppw == 4) { *err = general ? launch_full_general<D, CC, 16>(L, stream) : launch_full_c<D, CC, 16, true>(L, stream); return true; } } }

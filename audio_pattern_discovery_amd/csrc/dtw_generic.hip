@@ -277,7 +277,7 @@ hipError_t launch_unpack(const float *d_gathered, float *d_out, const uint32_t *
 struct Geometry { int g, c; };
 
 // Pick the (lanes per pair, offsets per lane) that wastes the fewest lanes for a band of `need` offsets; 0 = generic.
-int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen)
+int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen, bool fast_shift)
 {
     if (variant == 1) return 0;                                        // forced generic kernel
     if (variant >= 20000) variant = 0;                                 // a forced full-matrix geometry (pick_full_key) says nothing about band-form tiles
@@ -290,13 +290,18 @@ int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen
         const int g = variant / 100, c = variant % 100;
         return ((uint32_t)(g * c) >= need) ? variant : 0;
     }
-    static const Geometry all[] = {{16, 2}, {16, 3}, {16, 5}, {16, 7}, {16, 9}, {32, 5}, {32, 7}, {32, 9}, {64, 3}, {64, 5}, {64, 7}, {64, 9}};   // (8, 9) only on request
+    // score = lanes busy x how cheap a cell is at this C.  A macro-step costs about 116 SIMD cycles (window moves, exchanges,
+    // threshold test) plus 76 per cell pair, so relative to C = 9 a cell costs 1.04 / 1.11 / 1.29 / 1.50
+    // at C = 7 / 5 / 3 / 2.  G = 8 and G = 32 span half / two DPP rows: one-instruction moves only in the hybrid form with unit
+    // penalties (`fast_shift`: masked column fetch), two instructions or a select per move otherwise.
+    static const Geometry all[] = {{8, 5}, {8, 7}, {8, 9}, {16, 2}, {16, 3}, {16, 5}, {16, 7}, {16, 9}, {32, 5}, {32, 7}, {32, 9}, {64, 3}, {64, 5}, {64, 7}, {64, 9}};
+    auto cell_eff = [](int c) { return c >= 9 ? 1.0 : c >= 7 ? 0.96 : c >= 5 ? 0.90 : c >= 3 ? 0.78 : 0.67; };
     Geometry best{0, 0};
     double best_util = 0.0;
     for (const Geometry &q : all) {
         if ((uint32_t)(q.g * q.c) < need || q.c > max_cells_per_lane(dim)) continue;
-        const double util = (double)need / (double)(q.g * q.c) - 0.004 * (9 - q.c)   // larger C: fewer exchanges per cell
-                            - (q.g == 32 ? 0.04 : 0.0);                                // G = 32: two DPP per cross-lane move
+        const bool split_rows = q.g == 8 || q.g == 32;
+        const double util = (double)need / (double)(q.g * q.c) * cell_eff(q.c) * (split_rows ? (fast_shift ? 0.99 : 0.90) : 1.0);
         if (util > best_util) { best_util = util; best = q; }
     }
     if (best.g != 0) return best.g * 100 + best.c;
@@ -390,7 +395,7 @@ static hipError_t launch_align_chunk(const AlignLaunch &L, int geom_key, hipStre
     *status = APD_OK;
     if (L.n_tiles == 0) return hipSuccess;
     const BandSpec &b = L.band;
-    const bool unit = (b.ins == 1.0f) && (b.del == 1.0f) && (b.mat == 1.0f);   // the systolic kernel's UNIFORM_PEN path: no weighting at all
+    const bool unit = (b.ins == 1.0f) && (b.del == 1.0f) && (b.mat == 1.0f) && !L.strict;   // the systolic kernel's UNIFORM_PEN path: no weighting at all
     bool done = false;
     AlignLaunch LL = L;
     // The norm expansion trades D - 1 vector ops per cell (systolic kernel, pre-scaled rows; D - 4 in the strip kernels) for a

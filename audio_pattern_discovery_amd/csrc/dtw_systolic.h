@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     // that read across a row boundary, and the rows that end a group and must keep the fetched frame).  Instead the whole wave
     // shifts by one lane with ONE instruction -- the two group-top lanes receive a frame of the neighbouring pair or keep a
     // stale one -- and only those lanes then fetch their entering column, under EXEC, on top of it.
-    constexpr bool MASKED_FETCH = HYBRID && G == 32 && !(APD_ABLATE & 512);
+    // G = 8 (two groups per DPP row) is the same case one level down: row_shl instead of wave_shl.
+    constexpr bool MASKED_FETCH = HYBRID && (G == 32 || G == 8) && !(APD_ABLATE & 512);
     const int total_r = ((total + U - 1) / U) * U;
     const int a_end = min(((G + U - 1) / U) * U, total_r);
     const int b_end = min(max((min_rows / U) * U, a_end), total_r);
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
 #pragma unroll
         for (int k = 0; k < (HYBRID ? DN : D); ++k) {
             if (APD_ABLATE & 4) { yf[e][k] = yf[(r + 1) % S][k] + yf[e][k]; continue; }
-            yf[e][k] = MASKED_FETCH ? dpp_move<0x130>(yf[(r + 1) % S][k], yf[e][k])      // wave_shl:1, every row
+            yf[e][k] = MASKED_FETCH ? dpp_move<(G == 8) ? 0x101 : 0x130>(yf[(r + 1) % S][k], yf[e][k])   // row_shl:1 / wave_shl:1, every row
                                     : group_from_upper<G>(yf[(r + 1) % S][k], yf[e][k], gl);
         }
     };
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                 // receive is either +INF already or never looked at: lane 0's DELETE/INSERT neighbour comes from offset
                 // G*C - 1 >= 2w, outside DP1's band and therefore +INF (guarded nodes sit on their +INF MATCH predecessor), and
                 // its DP2 node (u = 0) is guarded itself; lane G-1's last node is guarded in DP1, and in DP2 either guarded
-                // (G*C - 1 > 2w) or handed lane 0's guarded u = 0 node, +INF.  (G = 32: the rotation spans the wave; the nodes
+                // (G*C - 1 > 2w) or handed lane 0's guarded u = 0 node, +INF.  (G = 8, 32: the rotation spans two groups / the wave; the nodes
                 // that wrap in come from the neighbouring group's edges, which meet the same conditions -- G*C >= 2w + 1 holds
                 // for every pair of the tile, and idle groups sweep a 1 x 1 dummy with w = 2.)
                 float left1 = group_from_lower_wrap<G>(prev1[C - 1], APD_INF, gl);
@@ -484,7 +485,7 @@ bool launch_systolic(const AlignLaunch &L, int g, int c, bool unit, hipStream_t 
 {
     // C = 9 keeps 10 column frames per lane in registers: only for D <= 13 (max_cells_per_lane)
 #define APD_CASE(GG, CC) if constexpr (CC <= max_cells_per_lane(D)) { if (g == GG && c == CC) { launch_systolic_cg<D, CC, GG>(L, unit, stream); return true; } }
-    APD_CASE(8, 9)
+    APD_CASE(8, 5) APD_CASE(8, 7) APD_CASE(8, 9)
     APD_CASE(16, 2) APD_CASE(16, 3) APD_CASE(16, 5) APD_CASE(16, 7) APD_CASE(16, 9)
     APD_CASE(32, 5) APD_CASE(32, 7) APD_CASE(32, 9)
     APD_CASE(64, 3) APD_CASE(64, 5) APD_CASE(64, 7) APD_CASE(64, 9)

@@ -81,7 +81,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per leg (0 = skip)")
     ap.add_argument("--verify", type=int, default=64, help="entries re-checked against the oracle after timing")
-    ap.add_argument("--distance", default="hybrid", choices=["hybrid", "exact"], help="local-distance form (apd_set_distance_mode)")
+    ap.add_argument("--distance", default="hybrid", choices=["hybrid", "exact", "strict"], help="local-distance form (apd_set_distance_mode); strict = the reference's arithmetic, bit-identical")
     ap.add_argument("--tau", type=float, default=0.0, help="hybrid recomputation threshold (0 = library default 1/64)")
     ap.add_argument("--cluster", action="store_true", help="also time percentile + UPGMA (rank 0, outside the timed region)")
     ap.add_argument("--backend", default="apd", choices=["apd", "nccl", "gloo"],

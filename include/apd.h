@@ -98,7 +98,14 @@ int apd_set_variant(apd_context *ctx, int variant);
  * per cell, ~3e-7 relative measured (tolerance asked: 1e-4); exact copies score exactly 0 in both.
  * With any other penalties the recurrence is discontinuous in its inputs (the penalty added depends on which
  * predecessor wins a strict comparison), so the library ignores the mode and computes operation for operation as
- * numerics.rs:114-120 / alignments.rs:129-160 do: results are then bit-identical to the CPU arithmetic. */
+ * numerics.rs:114-120 / alignments.rs:129-160 do: results are then bit-identical to the CPU arithmetic.
+ * mode 2 (strict): that operation-for-operation arithmetic for unit penalties as well -- every score bit-identical to the
+ * CPU code, about 2.5x slower.  What it buys over modes 0 / 1: the reference resolves an EXACT tie between the DELETE and
+ * INSERT predecessors by taking MATCH even when MATCH is larger; when such a tie arises by coincidence of two rounded
+ * f32 sums (real-valued features: about one matrix entry in 5 million on short sequences, tools/debug/fuzz.py), modes 0 / 1
+ * -- whose distances differ in the last bit -- do not see a tie and keep the smaller predecessor, and that one entry can
+ * differ by a few 1e-4 relative.  Ties that are structural (identical frames, integer features, +INF) are reproduced in
+ * every mode. */
 int apd_set_distance_mode(apd_context *ctx, int mode, float tau);
 /* Device self-test of the cross-lane primitives the kernels rely on (DPP wave shifts). */
 int apd_selftest(apd_context *ctx);

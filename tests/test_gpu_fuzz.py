@@ -69,3 +69,55 @@ def test_random_configurations_match_the_oracle(apd, oracle, seed):
     finally:
         ctx.close()
     assert not failures, failures[:3]
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_strict_mode_is_bit_identical_for_every_penalty_set(apd, oracle, seed):
+    """apd_set_distance_mode(ctx, 2): the reference's arithmetic operation for operation with UNIT (and equal) penalties too."""
+    from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
+    from audio_pattern_discovery_amd.discovery import Discovery
+    ctx = apd.Context(0)
+    failures = []
+    try:
+        ctx.set_distance_mode("strict")
+        for k, c in enumerate(_cases(seed, 40)):
+            frames, offsets = synth.make_sequences(c["n_seq"], c["length"], c["dim"], seed=c["seed"], integer=c["integer"],
+                                                   jitter=c["jitter"], copies=c["copies"])
+            ins, dele, mat = c["pens"] if k % 2 else (1.0, 1.0, 1.0)
+            want = oracle.align_all(frames, offsets, c["pct"], ins, dele, mat, workers=8)
+            seqs = [NDSequence(s) for s in synth.split(frames, offsets)]
+            got = AlignmentWorkers.new(seqs, ctx).align_all(
+                Discovery(warping_band_percentage=c["pct"], insertion_penalty=ins, deletion_penalty=dele,
+                          match_penalty=mat)).reshape(c["n_seq"], c["n_seq"])
+            if not np.array_equal(got, want):
+                failures.append((k, c))
+    finally:
+        ctx.close()
+    assert not failures, failures[:3]
+
+
+def test_coincidental_exact_tie_of_two_rounded_sums(apd, oracle):
+    """tools/debug/fuzz.py 2500 4242, case 1756: real-valued 15-dim features, unit penalties, 1 % band.  In the reference's f32
+    arithmetic the DELETE and INSERT predecessors of one node of pair (24, 32) are EXACTLY equal by coincidence of two rounded
+    sums, and the reference then takes MATCH although it is larger (alignments.rs:153-159).  The fast distance forms differ from
+    the CPU arithmetic in the last bit, see no tie there and keep the smaller predecessor: that entry is 2.4e-4 off (every other
+    entry of the matrix is within 3e-7).  The strict mode reproduces the reference's bits, tie included."""
+    from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
+    from audio_pattern_discovery_amd.discovery import Discovery
+    n_seq, dim, pct = 44, 15, 0.01
+    frames, offsets = synth.make_sequences(n_seq, 150, dim, seed=349714895, integer=False, jitter=35, copies=0.0)
+    want = oracle.align_all(frames, offsets, pct, 1.0, 1.0, 1.0, workers=8)
+    seqs = [NDSequence(s) for s in synth.split(frames, offsets)]
+    ctx = apd.Context(0)
+    try:
+        ctx.set_distance_mode("strict")
+        got = AlignmentWorkers.new(seqs, ctx).align_all(Discovery(warping_band_percentage=pct)).reshape(n_seq, n_seq)
+        assert np.array_equal(got, want)
+        ctx.set_distance_mode("hybrid")
+        fast = AlignmentWorkers.new(seqs, ctx).align_all(Discovery(warping_band_percentage=pct)).reshape(n_seq, n_seq)
+    finally:
+        ctx.close()
+    m = np.isfinite(want) & (want != 0)
+    rel = np.abs(fast - want)[m] / np.abs(want[m])
+    assert (rel > 1e-4).sum() <= 2 and rel.max() < 1e-3          # the tie, in both ordered directions; known and documented
+    assert np.sort(rel)[-3] < 1e-6
