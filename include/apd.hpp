@@ -37,6 +37,8 @@ class Context {
     Context(const Context &) = delete;
     Context &operator=(const Context &) = delete;
     apd_context *get() const { return ctx_; }
+    // 0 difference form, 1 hybrid (default), 2 strict: the Rust build's bits for every penalty set (apd.h, apd_set_distance_mode)
+    void set_distance_mode(int mode, float tau = 0.0f) { check(apd_set_distance_mode(ctx_, mode, tau)); }
   private:
     apd_context *ctx_ = nullptr;
 };
