@@ -98,6 +98,26 @@ SYMBOLS = [
     ("apd_all_gather_async", C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64]),
     ("apd_align_all_multi", C.c_int, [C.POINTER(C.c_int), C.c_uint32, _f32p, _u64p, C.c_uint32, C.c_uint32,
                                       C.POINTER(AlignConfig), _f32p, _u32p]),
+    ("apd_multi_create", C.c_int, [C.POINTER(C.c_int), C.c_uint32, C.POINTER(_vp)]),
+    ("apd_multi_destroy", C.c_int, [_vp]),
+    ("apd_multi_size", C.c_uint32, [_vp]),
+    ("apd_multi_ranks_seen", C.c_int, [_vp, _u32p]),
+    ("apd_multi_collective", C.c_char_p, [_vp]),
+    ("apd_multi_last_error", C.c_char_p, [_vp]),
+    ("apd_multi_context", _vp, [_vp, C.c_uint32]),
+    ("apd_multi_batch_create", C.c_int, [_vp, _vp, C.POINTER(_vp), _u64p, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
+    ("apd_multi_batch_refill", C.c_int, [_vp, _vp, _vp, C.POINTER(_vp)]),
+    ("apd_multi_batch_destroy", C.c_int, [_vp]),
+    ("apd_multi_align_all_async", C.c_int, [_vp, _vp, C.POINTER(AlignConfig), _vp]),
+    ("apd_multi_synchronize", C.c_int, [_vp]),
+    ("apd_multi_result", _vp, [_vp]),
+    ("apd_multi_align_all", C.c_int, [_vp, _vp, C.POINTER(AlignConfig), _f32p]),
+    ("apd_device_alloc", C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
+    ("apd_device_free", C.c_int, [_vp, _vp]),
+    ("apd_copy_to_device", C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    ("apd_copy_to_host", C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    ("apd_device_fill", C.c_int, [_vp, _vp, C.c_int, C.c_uint64]),
+    ("apd_runtime_info", C.c_uint64, [C.c_char_p, C.c_uint64]),
     ("apd_discovery_alignment_params", C.c_int, [C.POINTER(AlignConfig), C.c_uint64, C.POINTER(AlignmentParamsC)]),
     ("apd_batch_create", C.c_int, [_vp, _vp, _u64p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_vp)]),
     ("apd_batch_destroy", C.c_int, [_vp]),
@@ -164,10 +184,22 @@ def check(status, ctx_handle=None):
         raise ApdError(status, detail)
 
 
+def runtime_info():
+    """apd_runtime_info: the HIP and RCCL libraries (path, version) the library's calls are bound to in this process."""
+    n = int(lib().apd_runtime_info(None, 0))
+    buf = C.create_string_buffer(n)
+    lib().apd_runtime_info(buf, n)
+    return buf.value.decode()
+
+
 class Context:
     """apd_context: one GPU, one HIP stream."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, borrowed=None):
+        self._borrowed = borrowed is not None                # a context owned by an apd_multi handle: never destroyed here
+        if self._borrowed:
+            self.handle = _vp(int(borrowed))
+            return
         self.handle = _vp()
         check(lib().apd_create(int(device), C.byref(self.handle)))
         if stream is not None:
@@ -175,8 +207,19 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
-            lib().apd_destroy(self.handle)
+            if not self._borrowed:
+                lib().apd_destroy(self.handle)
             self.handle = None
+
+    def alloc(self, nbytes):
+        """apd_device_alloc: a DeviceBuffer of nbytes in this context's HBM."""
+        return DeviceBuffer(self, nbytes)
+
+    def upload(self, array):
+        """A DeviceBuffer holding a copy of the (contiguous) numpy array."""
+        buf = DeviceBuffer(self, array.nbytes)
+        buf.copy_from(array)
+        return buf
 
     def __del__(self):
         try:
@@ -208,6 +251,54 @@ class Context:
     def set_fault_injection(self, drop_tiles):
         """TEST HOOK: the next alignment launches skip the last `drop_tiles` tiles of every kernel class."""
         check(lib().apd_set_fault_injection(self.handle, int(drop_tiles)))
+
+
+class DeviceBuffer:
+    """HBM owned through the C ABI (apd_device_alloc / _free / apd_copy_to_*): what the tests and bench.py keep features and
+    matrices resident in -- no torch anywhere near the data path."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        self._p = _vp()
+        check(lib().apd_device_alloc(ctx.handle, self.nbytes, C.byref(self._p)), ctx.handle)
+
+    @property
+    def ptr(self):
+        return self._p.value or 0
+
+    def at(self, byte_offset=0):
+        return _vp(self.ptr + int(byte_offset))
+
+    def copy_from(self, array, byte_offset=0):
+        import numpy as np
+        a = np.ascontiguousarray(array)
+        if byte_offset + a.nbytes > self.nbytes:
+            raise ValueError("copy past the end of the device buffer")
+        check(lib().apd_copy_to_device(self.ctx.handle, self.at(byte_offset), _vp(a.ctypes.data), a.nbytes), self.ctx.handle)
+
+    def to_numpy(self, dtype, count=None, byte_offset=0):
+        import numpy as np
+        dt = np.dtype(dtype)
+        count = (self.nbytes - byte_offset) // dt.itemsize if count is None else int(count)
+        out = np.empty(count, dtype=dt)
+        if byte_offset + out.nbytes > self.nbytes:
+            raise ValueError("copy past the end of the device buffer")
+        check(lib().apd_copy_to_host(self.ctx.handle, _vp(out.ctypes.data), self.at(byte_offset), out.nbytes), self.ctx.handle)
+        return out
+
+    def fill(self, byte_value):
+        check(lib().apd_device_fill(self.ctx.handle, self._p, int(byte_value), self.nbytes), self.ctx.handle)
+
+    def free(self):
+        if getattr(self, "_p", None) and self._p.value and getattr(self.ctx, "handle", None):
+            lib().apd_device_free(self.ctx.handle, self._p)
+        self._p = _vp()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 _default_ctx = None

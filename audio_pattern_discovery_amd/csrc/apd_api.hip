@@ -770,3 +770,53 @@ extern "C" int apd_align_work(const uint64_t *offsets, uint32_t n_seq, uint32_t 
     if (alg_bytes) *alg_bytes = nb;
     return APD_OK;
 }
+
+// ------------------------------------------------------------------------------- device buffers
+
+extern "C" int apd_device_alloc(apd_context *ctx, uint64_t bytes, void **d_ptr)
+{
+    if (!ctx || !d_ptr) return APD_ERR_INVALID_ARG;
+    *d_ptr = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMalloc(d_ptr, std::max<size_t>((size_t)bytes, 16)));
+    return APD_OK;
+}
+
+extern "C" int apd_device_free(apd_context *ctx, void *d_ptr)
+{
+    if (!ctx) return APD_ERR_INVALID_ARG;
+    if (!d_ptr) return APD_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                      // nothing queued may still use it
+    HIP_TRY(ctx, hipFree(d_ptr));
+    return APD_OK;
+}
+
+extern "C" int apd_copy_to_device(apd_context *ctx, void *d_dst, const void *src, uint64_t bytes)
+{
+    if (!ctx || (bytes && (!d_dst || !src))) return APD_ERR_INVALID_ARG;
+    if (bytes == 0) return APD_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(d_dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return APD_OK;
+}
+
+extern "C" int apd_copy_to_host(apd_context *ctx, void *dst, const void *d_src, uint64_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !d_src))) return APD_ERR_INVALID_ARG;
+    if (bytes == 0) return APD_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return APD_OK;
+}
+
+extern "C" int apd_device_fill(apd_context *ctx, void *d_dst, int byte_value, uint64_t bytes)
+{
+    if (!ctx || (bytes && !d_dst)) return APD_ERR_INVALID_ARG;
+    if (bytes == 0) return APD_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemsetAsync(d_dst, byte_value, (size_t)bytes, ctx->stream));
+    return APD_OK;
+}

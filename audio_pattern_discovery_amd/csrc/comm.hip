@@ -4,9 +4,17 @@
 // No torch, no MPI: the 128-byte unique id travels over whatever channel the host has.
 #include <rccl/rccl.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -150,85 +158,367 @@ extern "C" int apd_align_all_sharded_async(apd_context *ctx, apd_comm *c, const 
     return apd_unpack_tiles_async(ctx, batch, c->world, gathered, d_out);
 }
 
-// One process, n_devices GPUs: ncclCommInitAll, one context and one resident copy of the batch per device, every device
-// aligns its share of the pair tiles on its own stream, one grouped all-gather, unpack on devices[0].
+// ---------------------------------------------------------------------------------------------------------------------
+// One process, n_devices GPUs, as a PERSISTENT handle (include/apd.h "as a persistent handle"): contexts, communicators,
+// worker threads, gather workspaces and resident batches are made once; an align_all pays kernels + one all-gather + unpack.
+
+namespace {
+
+// One host thread per device, alive as long as the handle: the counterpart of the reference's `alignment_workers` threads
+// (alignments.rs:35-41).  run(f) executes f(i) on worker i for every device at once and returns when all are done.
+class WorkerPool {
+public:
+    explicit WorkerPool(uint32_t n) : slots_(n > 1 ? n : 0)
+    {
+        for (uint32_t i = 0; i < slots_.size(); ++i) threads_.emplace_back([this, i] { loop(i); });
+    }
+    ~WorkerPool()
+    {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            quit_ = true;
+        }
+        cv_work_.notify_all();
+        for (std::thread &t : threads_) t.join();
+    }
+    void run(uint32_t n, const std::function<int(uint32_t)> &f, std::vector<int> &rc)
+    {
+        rc.assign(n, APD_OK);
+        if (slots_.empty()) {                                             // one device: no thread at all
+            for (uint32_t i = 0; i < n; ++i) rc[i] = f(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            task_ = &f; rc_ = &rc; pending_ = (uint32_t)slots_.size(); ++generation_;
+        }
+        cv_work_.notify_all();
+        std::unique_lock<std::mutex> g(mu_);
+        cv_done_.wait(g, [this] { return pending_ == 0; });
+        task_ = nullptr; rc_ = nullptr;
+    }
+
+private:
+    void loop(uint32_t i)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<int(uint32_t)> *f;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_work_.wait(g, [&] { return quit_ || generation_ != seen; });
+                if (quit_) return;
+                seen = generation_;
+                f = task_;
+            }
+            int r;
+            try { r = (*f)(i); } catch (...) { r = APD_ERR_OOM; }          // nothing may unwind out of a worker
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                (*rc_)[i] = r;
+                if (--pending_ == 0) cv_done_.notify_all();
+            }
+        }
+    }
+    std::vector<int> slots_;
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_work_, cv_done_;
+    const std::function<int(uint32_t)> *task_ = nullptr;
+    std::vector<int> *rc_ = nullptr;
+    uint32_t pending_ = 0;
+    uint64_t generation_ = 0;
+    bool quit_ = false;
+};
+
+}  // namespace
+
+struct apd_multi {
+    std::vector<int> devices;
+    std::vector<apd_context *> ctx;
+    std::vector<ncclComm_t> comms;                 // empty in the peer-copy fallback
+    std::vector<hipEvent_t> slab_ready;            // peer-copy fallback: device i's slab is complete (recorded on its stream)
+    hipEvent_t gathered = nullptr;                 //                     devices[0] has copied every slab of the last call
+    bool gathered_valid = false;
+    std::string collective, last_error;
+    std::set<apd_multi_batch *> batches;
+    float *d_result = nullptr;                     // matrix owned by the handle (apd_multi_align_all_async with d_out == NULL)
+    size_t result_bytes = 0;
+    const float *last_result = nullptr;
+    WorkerPool *pool = nullptr;
+};
+
+struct apd_multi_batch {
+    apd_multi *multi = nullptr;
+    std::vector<apd_batch *> per_device;
+    uint32_t n_seq = 0, dim = 0;
+};
+
+namespace {
+
+uint32_t nd(const apd_multi *m) { return (uint32_t)m->devices.size(); }
+
+// rc[] of a fan-out -> one status; the first failing device's text goes to the handle
+int merge_status(apd_multi *m, const std::vector<int> &rc)
+{
+    for (uint32_t i = 0; i < rc.size(); ++i)
+        if (rc[i] != APD_OK) {
+            m->last_error = "device " + std::to_string(m->devices[i]) + ": " + apd_status_string(rc[i]) +
+                            (m->ctx[i]->last_error.empty() ? "" : " (" + m->ctx[i]->last_error + ")");
+            return rc[i];
+        }
+    return APD_OK;
+}
+
+int multi_fail(apd_multi *m, int rc, const std::string &what)
+{
+    m->last_error = what;
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int apd_multi_create(const int *devices, uint32_t n_devices, apd_multi **out)
+{
+    if (!devices || n_devices == 0 || !out) return APD_ERR_INVALID_ARG;
+    *out = nullptr;
+    for (uint32_t i = 0; i < n_devices; ++i)
+        for (uint32_t j = 0; j < i; ++j)
+            if (devices[i] == devices[j]) return APD_ERR_INVALID_ARG;        // RCCL refuses two ranks on one device
+    apd_multi *m = new (std::nothrow) apd_multi();
+    if (!m) return APD_ERR_OOM;
+    m->devices.assign(devices, devices + n_devices);
+    m->ctx.assign(n_devices, nullptr);
+    int rc = APD_OK;
+    for (uint32_t i = 0; i < n_devices && rc == APD_OK; ++i) rc = apd_create(devices[i], &m->ctx[i]);
+    if (rc != APD_OK) { apd_multi_destroy(m); return rc; }
+    const char *force = std::getenv("APD_MULTI_COLLECTIVE");
+    std::string why;
+    if (force && std::strcmp(force, "peer") == 0) why = "APD_MULTI_COLLECTIVE=peer";
+    else {
+        m->comms.assign(n_devices, nullptr);
+        const ncclResult_t r = ncclCommInitAll(m->comms.data(), (int)n_devices, devices);
+        if (r != ncclSuccess) {
+            why = std::string("ncclCommInitAll: ") + ncclGetErrorString(r);
+            m->comms.clear();
+        }
+    }
+    if (!m->comms.empty()) {
+        int version = 0;
+        ncclGetVersion(&version);
+        m->collective = "rccl: ncclCommInitAll over " + std::to_string(n_devices) + " device(s), one grouped ncclAllGather per align_all (RCCL " +
+                        std::to_string(version) + ")";
+    } else {
+        m->collective = "peer-copy fallback: " + why + "; slabs gathered onto devices[0] with hipMemcpyPeerAsync";
+        m->slab_ready.assign(n_devices, nullptr);
+        for (uint32_t i = 0; i < n_devices; ++i) {
+            hipSetDevice(devices[i]);
+            if (hipEventCreateWithFlags(&m->slab_ready[i], hipEventDisableTiming) != hipSuccess) rc = APD_ERR_HIP;
+        }
+        hipSetDevice(devices[0]);
+        if (hipEventCreateWithFlags(&m->gathered, hipEventDisableTiming) != hipSuccess) rc = APD_ERR_HIP;
+        if (rc != APD_OK) { apd_multi_destroy(m); return rc; }
+    }
+    m->pool = new (std::nothrow) WorkerPool(n_devices);
+    if (!m->pool) { apd_multi_destroy(m); return APD_ERR_OOM; }
+    *out = m;
+    return APD_OK;
+}
+
+extern "C" int apd_multi_destroy(apd_multi *m)
+{
+    if (!m) return APD_ERR_INVALID_ARG;
+    for (apd_context *c : m->ctx) if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); }
+    delete m->pool;                                                       // joins the workers
+    m->pool = nullptr;
+    while (!m->batches.empty()) apd_multi_batch_destroy(*m->batches.begin());
+    for (ncclComm_t c : m->comms) if (c) ncclCommDestroy(c);
+    for (uint32_t i = 0; i < m->slab_ready.size(); ++i) if (m->slab_ready[i]) { hipSetDevice(m->devices[i]); hipEventDestroy(m->slab_ready[i]); }
+    if (m->gathered) { hipSetDevice(m->devices[0]); hipEventDestroy(m->gathered); }
+    if (m->d_result) { hipSetDevice(m->devices[0]); hipFree(m->d_result); }
+    for (apd_context *c : m->ctx) if (c) apd_destroy(c);
+    delete m;
+    return APD_OK;
+}
+
+extern "C" uint32_t apd_multi_size(const apd_multi *m) { return m ? nd(m) : 0; }
+
+extern "C" int apd_multi_ranks_seen(const apd_multi *m, uint32_t *ranks)
+{
+    if (!m || !ranks) return APD_ERR_INVALID_ARG;
+    if (m->comms.empty()) { *ranks = nd(m); return APD_OK; }
+    int cnt = 0;
+    if (ncclCommCount(m->comms[0], &cnt) != ncclSuccess) return APD_ERR_COMM;
+    *ranks = (uint32_t)cnt;
+    return APD_OK;
+}
+
+extern "C" const char *apd_multi_collective(const apd_multi *m) { return m ? m->collective.c_str() : "null handle"; }
+extern "C" const char *apd_multi_last_error(const apd_multi *m) { return m ? m->last_error.c_str() : "null handle"; }
+extern "C" apd_context *apd_multi_context(apd_multi *m, uint32_t i) { return (m && i < nd(m)) ? m->ctx[i] : nullptr; }
+extern "C" const float *apd_multi_result(const apd_multi *m) { return m ? m->last_result : nullptr; }
+
+extern "C" int apd_multi_batch_create(apd_multi *m, const float *frames, const float *const *d_frames, const uint64_t *offsets,
+                                      uint32_t n_seq, uint32_t dim, apd_multi_batch **out)
+{
+    if (!m || !offsets || !out) return APD_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (offsets[n_seq] > 0 && !frames && !d_frames) return APD_ERR_INVALID_ARG;
+    apd_multi_batch *mb = new (std::nothrow) apd_multi_batch();
+    if (!mb) return APD_ERR_OOM;
+    mb->multi = m; mb->n_seq = n_seq; mb->dim = dim;
+    mb->per_device.assign(nd(m), nullptr);
+    // every device holds the whole corpus (<= 2.1 GB at cfg 5): any pair tile can be aligned anywhere.  The workers upload
+    // concurrently, one PCIe link each.
+    std::vector<int> rc;
+    m->pool->run(nd(m), [&](uint32_t i) {
+        return apd_batch_create(m->ctx[i], d_frames ? d_frames[i] : frames, offsets, n_seq, dim, d_frames ? 1 : 0, &mb->per_device[i]);
+    }, rc);
+    const int st = merge_status(m, rc);
+    m->batches.insert(mb);
+    if (st != APD_OK) { apd_multi_batch_destroy(mb); return st; }
+    *out = mb;
+    return APD_OK;
+}
+
+extern "C" int apd_multi_batch_refill(apd_multi *m, apd_multi_batch *mb, const float *frames, const float *const *d_frames)
+{
+    if (!m || !mb || mb->multi != m) return APD_ERR_INVALID_ARG;
+    if (!frames && !d_frames && mb->n_seq) return APD_ERR_INVALID_ARG;
+    std::vector<int> rc;
+    m->pool->run(nd(m), [&](uint32_t i) {
+        return apd_batch_refill(m->ctx[i], mb->per_device[i], d_frames ? d_frames[i] : frames, d_frames ? 1 : 0);
+    }, rc);
+    return merge_status(m, rc);
+}
+
+extern "C" int apd_multi_batch_destroy(apd_multi_batch *mb)
+{
+    if (!mb) return APD_ERR_INVALID_ARG;
+    for (apd_batch *b : mb->per_device) if (b) apd_batch_destroy(b);
+    if (mb->multi) mb->multi->batches.erase(mb);
+    delete mb;
+    return APD_OK;
+}
+
+extern "C" int apd_multi_align_all_async(apd_multi *m, const apd_multi_batch *mb, const apd_align_config *cfg, float *d_out)
+{
+    if (!m || !mb || !cfg || mb->multi != m) return APD_ERR_INVALID_ARG;
+    const uint32_t n = nd(m), n_seq = mb->n_seq;
+    if (n_seq == 0) return APD_OK;
+    const uint64_t slab = apd_slab_floats(n_seq, n);
+    const size_t gather_bytes = std::max<size_t>((size_t)slab * n * sizeof(float), 16);
+    if (!d_out) {                                                          // the handle's own result matrix on devices[0]
+        const size_t need = (size_t)n_seq * n_seq * sizeof(float);
+        if (m->result_bytes < need) {
+            hipSetDevice(m->devices[0]);
+            if (m->d_result) { hipStreamSynchronize(m->ctx[0]->stream); hipFree(m->d_result); m->d_result = nullptr; m->result_bytes = 0; }
+            if (hipMalloc((void **)&m->d_result, need) != hipSuccess) return multi_fail(m, APD_ERR_OOM, "device " + std::to_string(m->devices[0]) + ": result matrix");
+            m->result_bytes = need;
+        }
+        d_out = m->d_result;
+    }
+    const bool peer = m->comms.empty();
+    // 1. every device: its pair tiles into its slab, in place inside its gather buffer
+    std::vector<int> rc;
+    m->pool->run(n, [&](uint32_t i) {
+        apd_context *c = m->ctx[i];
+        if (hipSetDevice(c->device) != hipSuccess) return (int)APD_ERR_HIP;
+        int r = ensure_gather(c, gather_bytes);
+        if (r != APD_OK) return r;
+        // peer fallback: devices[0] must have copied this device's previous slab before it is poisoned again
+        if (peer && i != 0 && m->gathered_valid && hipStreamWaitEvent(c->stream, m->gathered, 0) != hipSuccess) return (int)APD_ERR_HIP;
+        r = apd_align_tiles_async(c, mb->per_device[i], cfg, i, n, (float *)c->ws_gather + (size_t)slab * i);
+        if (r == APD_OK && peer && hipEventRecord(m->slab_ready[i], c->stream) != hipSuccess) r = APD_ERR_HIP;
+        return r;
+    }, rc);
+    int st = merge_status(m, rc);
+    if (st != APD_OK) return st;
+    // 2. ONE all-gather of the equal-sized slabs (in place: sendbuff = recvbuff + i * slab), grouped over the devices
+    if (!peer) {
+        ncclResult_t r = ncclGroupStart();
+        for (uint32_t i = 0; i < n && r == ncclSuccess; ++i) {
+            float *g = (float *)m->ctx[i]->ws_gather;
+            r = ncclAllGather(g + (size_t)slab * i, g, (size_t)slab, ncclFloat, m->comms[i], m->ctx[i]->stream);
+        }
+        const ncclResult_t r2 = ncclGroupEnd();
+        if (r != ncclSuccess || r2 != ncclSuccess)
+            return multi_fail(m, APD_ERR_COMM, std::string("ncclAllGather: ") + ncclGetErrorString(r != ncclSuccess ? r : r2));
+    } else {
+        apd_context *c0 = m->ctx[0];
+        hipSetDevice(c0->device);
+        float *g0 = (float *)c0->ws_gather;
+        for (uint32_t i = 1; i < n; ++i) {
+            const float *gi = (const float *)m->ctx[i]->ws_gather + (size_t)slab * i;
+            if (hipStreamWaitEvent(c0->stream, m->slab_ready[i], 0) != hipSuccess ||
+                hipMemcpyPeerAsync(g0 + (size_t)slab * i, c0->device, gi, m->ctx[i]->device, (size_t)slab * sizeof(float), c0->stream) != hipSuccess)
+                return multi_fail(m, APD_ERR_HIP, "device " + std::to_string(m->devices[i]) + ": peer copy of the slab failed");
+        }
+        if (hipEventRecord(m->gathered, c0->stream) != hipSuccess) return multi_fail(m, APD_ERR_HIP, "hipEventRecord(gathered)");
+        m->gathered_valid = true;
+    }
+    // 3. unpack on devices[0] (rank 0 is the consumer: UPGMA runs there)
+    st = apd_unpack_tiles_async(m->ctx[0], mb->per_device[0], n, (const float *)m->ctx[0]->ws_gather, d_out);
+    if (st != APD_OK) { rc.assign(n, APD_OK); rc[0] = st; return merge_status(m, rc); }
+    m->last_result = d_out;
+    return APD_OK;
+}
+
+extern "C" int apd_multi_synchronize(apd_multi *m)
+{
+    if (!m) return APD_ERR_INVALID_ARG;
+    std::vector<int> rc(nd(m), APD_OK);
+    for (uint32_t i = 0; i < nd(m); ++i) rc[i] = apd_synchronize(m->ctx[i]);   // also reports APD_ERR_INCOMPLETE (devices[0] unpacks)
+    return merge_status(m, rc);
+}
+
+extern "C" int apd_multi_align_all(apd_multi *m, const apd_multi_batch *mb, const apd_align_config *cfg, float *out)
+{
+    if (!m || !mb || !cfg || mb->multi != m || (!out && mb->n_seq)) return APD_ERR_INVALID_ARG;
+    if (mb->n_seq == 0) return APD_OK;
+    int rc = apd_multi_align_all_async(m, mb, cfg, nullptr);
+    if (rc != APD_OK) { apd_multi_synchronize(m); return rc; }
+    apd_context *c0 = m->ctx[0];
+    hipSetDevice(c0->device);
+    if (hipMemcpyAsync(out, m->last_result, (size_t)mb->n_seq * mb->n_seq * sizeof(float), hipMemcpyDeviceToHost, c0->stream) != hipSuccess)
+        rc = multi_fail(m, APD_ERR_HIP, "device " + std::to_string(c0->device) + ": copy of the matrix to the host failed");
+    const int rs = apd_multi_synchronize(m);
+    return rc != APD_OK ? rc : rs;
+}
+
+// One-shot form: everything above made and torn down inside one call (kept for callers that align once).
 extern "C" int apd_align_all_multi(const int *devices, uint32_t n_devices, const float *frames, const uint64_t *offsets, uint32_t n_seq,
                                    uint32_t dim, const apd_align_config *cfg, float *out, uint32_t *ranks_seen)
 {
     if (!devices || n_devices == 0 || !offsets || !cfg || (n_seq && !out)) return APD_ERR_INVALID_ARG;
-    for (uint32_t i = 0; i < n_devices; ++i)
-        for (uint32_t j = 0; j < i; ++j)
-            if (devices[i] == devices[j]) return APD_ERR_INVALID_ARG;        // RCCL refuses two ranks on one device
-    std::vector<apd_context *> ctx(n_devices, nullptr);
-    std::vector<apd_batch *> batch(n_devices, nullptr);
-    std::vector<ncclComm_t> comms(n_devices, nullptr);
-    float *d_out = nullptr;
-    bool comms_live = false;
-    int rc = APD_OK;
-    auto cleanup = [&]() {
-        for (uint32_t i = 0; i < n_devices; ++i) if (ctx[i]) { hipSetDevice(ctx[i]->device); hipStreamSynchronize(ctx[i]->stream); }
-        if (comms_live) for (uint32_t i = 0; i < n_devices; ++i) if (comms[i]) ncclCommDestroy(comms[i]);
-        if (d_out) { hipSetDevice(ctx[0]->device); hipFree(d_out); }
-        for (uint32_t i = 0; i < n_devices; ++i) {
-            if (batch[i]) apd_batch_destroy(batch[i]);
-            if (ctx[i]) apd_destroy(ctx[i]);
-        }
-    };
-    for (uint32_t i = 0; i < n_devices && rc == APD_OK; ++i) rc = apd_create(devices[i], &ctx[i]);
-    if (rc == APD_OK && ncclCommInitAll(comms.data(), (int)n_devices, devices) != ncclSuccess) rc = APD_ERR_COMM;
-    else if (rc == APD_OK) comms_live = true;
-    if (rc == APD_OK && ranks_seen) {
-        int cnt = 0;
-        if (ncclCommCount(comms[0], &cnt) != ncclSuccess) rc = APD_ERR_COMM;
-        *ranks_seen = (uint32_t)cnt;
-    }
-    // every device holds the whole corpus (<= 2.1 GB at cfg 5): any pair tile can be aligned anywhere.  One host thread per
-    // device uploads the batch and enqueues that device's pair tiles: the uploads run over eight PCIe links at once instead of
-    // one after the other (cfg 3: 218 MB per device, a fifth of a device's share of the alignment time each).
-    const uint64_t slab = n_seq ? apd_slab_floats(n_seq, n_devices) : 0;
-    const size_t gather_bytes = std::max<size_t>((size_t)slab * n_devices * sizeof(float), 16);
-    if (rc == APD_OK) {
-        std::vector<int> drc(n_devices, APD_OK);
-        auto per_device = [&](uint32_t i) {
-            int r = apd_batch_create(ctx[i], frames, offsets, n_seq, dim, 0, &batch[i]);
-            if (r == APD_OK && n_seq > 0) {
-                r = hipSetDevice(ctx[i]->device) == hipSuccess ? APD_OK : APD_ERR_HIP;
-                if (r == APD_OK) r = ensure_gather(ctx[i], gather_bytes);
-                if (r == APD_OK) r = apd_align_tiles_async(ctx[i], batch[i], cfg, i, n_devices, (float *)ctx[i]->ws_gather + (size_t)slab * i);
-            }
-            drc[i] = r;
-        };
-        std::vector<std::thread> workers;
-        for (uint32_t i = 1; i < n_devices; ++i) workers.emplace_back(per_device, i);
-        per_device(0);
-        for (std::thread &t : workers) t.join();
-        for (uint32_t i = 0; i < n_devices; ++i)
-            if (drc[i] != APD_OK && rc == APD_OK) { rc = drc[i]; if (i != 0) ctx[0]->last_error = "device " + std::to_string(devices[i]) + ": " + ctx[i]->last_error; }
-    }
-    if (rc == APD_OK && n_seq > 0) {
-        if (rc == APD_OK) {
-            ncclResult_t r = ncclGroupStart();
-            for (uint32_t i = 0; i < n_devices && r == ncclSuccess; ++i) {
-                hipSetDevice(ctx[i]->device);
-                float *g = (float *)ctx[i]->ws_gather;
-                r = ncclAllGather(g + (size_t)slab * i, g, (size_t)slab, ncclFloat, comms[i], ctx[i]->stream);
-            }
-            const ncclResult_t r2 = ncclGroupEnd();
-            if (r != ncclSuccess || r2 != ncclSuccess) {
-                ctx[0]->last_error = std::string("ncclAllGather: ") + ncclGetErrorString(r != ncclSuccess ? r : r2);
-                rc = APD_ERR_COMM;
-            }
-        }
-        if (rc == APD_OK) {
-            hipSetDevice(ctx[0]->device);
-            const size_t bytes = (size_t)n_seq * n_seq * sizeof(float);
-            if (hipMalloc((void **)&d_out, bytes) != hipSuccess) rc = APD_ERR_OOM;
-            if (rc == APD_OK) rc = apd_unpack_tiles_async(ctx[0], batch[0], n_devices, (const float *)ctx[0]->ws_gather, d_out);
-            if (rc == APD_OK && hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx[0]->stream) != hipSuccess) rc = APD_ERR_HIP;
-            if (rc == APD_OK) rc = apd_synchronize(ctx[0]);               // also reports APD_ERR_INCOMPLETE
-        }
-        for (uint32_t i = 1; i < n_devices; ++i) { const int r = apd_synchronize(ctx[i]); if (rc == APD_OK) rc = r; }
-    }
-    cleanup();
+    apd_multi *m = nullptr;
+    int rc = apd_multi_create(devices, n_devices, &m);
+    if (rc != APD_OK) return rc;
+    if (ranks_seen) rc = apd_multi_ranks_seen(m, ranks_seen);
+    apd_multi_batch *mb = nullptr;
+    if (rc == APD_OK) rc = apd_multi_batch_create(m, frames, nullptr, offsets, n_seq, dim, &mb);
+    if (rc == APD_OK) rc = apd_multi_align_all(m, mb, cfg, out);
+    if (rc != APD_OK) std::fprintf(stderr, "[apd] apd_align_all_multi: %s\n", apd_multi_last_error(m));   // the handle (and its text) dies here
+    apd_multi_destroy(m);
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------------------ runtime identity
+extern "C" uint64_t apd_runtime_info(char *out, uint64_t capacity)
+{
+    auto path_of = [](const void *sym) -> std::string {
+        Dl_info info;
+        return (dladdr(sym, &info) && info.dli_fname) ? info.dli_fname : "?";
+    };
+    int hip_version = 0, nccl_version = 0;
+    hipRuntimeGetVersion(&hip_version);
+    ncclGetVersion(&nccl_version);
+    const std::string text = "hip " + std::to_string(hip_version) + " @ " + path_of((const void *)&hipStreamSynchronize) + "; rccl " +
+                             std::to_string(nccl_version) + " @ " + path_of((const void *)&ncclAllGather);
+    if (out && capacity) {
+        const size_t k = std::min<size_t>(text.size(), (size_t)capacity - 1);
+        std::memcpy(out, text.data(), k);
+        out[k] = '\0';
+    }
+    return text.size() + 1;
 }

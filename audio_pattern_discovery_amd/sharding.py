@@ -107,6 +107,96 @@ class Comm:
             pass
 
 
+class Multi:
+    """apd_multi: ONE process driving len(devices) GPUs through a persistent handle -- contexts, the RCCL communicators of
+    ncclCommInitAll, one worker thread per device and the gather workspaces are made once (AlignmentWorkers over N GPUs,
+    reference alignments.rs:11-67)."""
+
+    def __init__(self, devices):
+        self.devices = [int(d) for d in devices]
+        self.handle = C.c_void_p()
+        devs = (C.c_int * len(self.devices))(*self.devices)
+        _lib.check(_lib.lib().apd_multi_create(devs, len(self.devices), C.byref(self.handle)))
+        self.contexts = [_lib.Context(borrowed=_lib.lib().apd_multi_context(self.handle, i)) for i in range(len(self.devices))]
+
+    def _check(self, status):
+        if status != _lib.APD_OK:
+            raise _lib.ApdError(status, _lib.lib().apd_multi_last_error(self.handle).decode())
+
+    def ranks_seen(self):
+        n = C.c_uint32(0)
+        self._check(_lib.lib().apd_multi_ranks_seen(self.handle, C.byref(n)))
+        return int(n.value)
+
+    def collective(self):
+        return _lib.lib().apd_multi_collective(self.handle).decode()
+
+    def batch(self, offsets, dim, frames=None, d_frames=None):
+        return MultiBatch(self, offsets, dim, frames, d_frames)
+
+    def align_all_async(self, batch, cfg, d_out_ptr=None):
+        self._check(_lib.lib().apd_multi_align_all_async(self.handle, batch.handle, C.byref(cfg), C.c_void_p(int(d_out_ptr)) if d_out_ptr else None))
+
+    def align_all(self, batch, cfg):
+        out = np.empty((batch.n_seq, batch.n_seq), dtype=np.float32)
+        self._check(_lib.lib().apd_multi_align_all(self.handle, batch.handle, C.byref(cfg), out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def result_ptr(self):
+        return _lib.lib().apd_multi_result(self.handle) or 0
+
+    def synchronize(self):
+        self._check(_lib.lib().apd_multi_synchronize(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.lib().apd_multi_destroy(self.handle)
+            self.handle = None
+            for c in self.contexts:
+                c.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiBatch:
+    """apd_multi_batch: the corpus resident on every device of a Multi."""
+
+    def __init__(self, multi, offsets, dim, frames=None, d_frames=None):
+        self.multi = multi
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.n_seq = len(self.offsets) - 1
+        self.handle = C.c_void_p()
+        host, dev = self._args(frames, d_frames)
+        multi._check(_lib.lib().apd_multi_batch_create(multi.handle, host, dev, self.offsets.ctypes.data_as(C.POINTER(C.c_uint64)), self.n_seq,
+                                                       int(dim), C.byref(self.handle)))
+
+    def _args(self, frames, d_frames):
+        if d_frames is not None:
+            self._dev = (C.c_void_p * len(d_frames))(*[int(p) for p in d_frames])
+            return None, self._dev
+        self._host = np.ascontiguousarray(frames, dtype=np.float32)
+        return C.c_void_p(self._host.ctypes.data), None
+
+    def refill(self, frames=None, d_frames=None):
+        host, dev = self._args(frames, d_frames)
+        self.multi._check(_lib.lib().apd_multi_batch_refill(self.multi.handle, self.handle, host, dev))
+
+    def close(self):
+        if getattr(self, "handle", None) and getattr(self.multi, "handle", None):
+            _lib.lib().apd_multi_batch_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def align_all_multi(devices, frames, offsets, dim, cfg):
     """apd_align_all_multi: ONE process, len(devices) GPUs (ncclCommInitAll).  Returns ((n, n) matrix, ranks RCCL saw)."""
     off = np.ascontiguousarray(offsets, dtype=np.uint64)

@@ -1,30 +1,38 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: all-pairs Sakoe-Chiba-banded DTW distance matrix (reference
-src/alignments.rs:31-67) on synthetic MFCC-like sequences, one process per GPU.
+src/alignments.rs:31-67) on synthetic MFCC-like sequences.  NO torch anywhere: device buffers, streams,
+the RCCL communicators and the timing fences all come from libapd_hip.so through its C ABI (include/apd.h).
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
 
-A step = one full pass of the path over the resident batch: repack the [sum len][D] frames into
-the kernels' padded layout (apd_batch_refill), fused-pair DTW over this rank's pair tiles, ONE
-ncclAllGather of the packed tile slabs, unpack into the N x N matrix -- the last three are ONE call,
-apd_align_all_sharded_async, on a communicator the LIBRARY owns (apd_comm_create: RCCL over xGMI,
-include/apd.h).  The pair set is fixed as ranks are added (strong scaling).  torch is plumbing
-only: device buffers, the stream, and a gloo process group for the control plane (handing the
-128-byte communicator id to the ranks, barriers, the max over ranks of the elapsed time); the
-compute AND the data-path collective are libapd_hip.so through its C ABI.  If the library's
-communicator cannot be made on some rank, every rank falls back to torch.distributed's "nccl"
-all_gather_into_tensor and the JSON line says so ("collective").
+How N GPUs are driven:
+  * WORLD_SIZE unset (how the driver starts it):  ONE process drives the N devices through the library's
+    persistent multi-device handle (apd_multi_create: one context + worker thread per device, ncclCommInitAll,
+    resident batches and gather buffers made once; a step = apd_multi_batch_refill + apd_multi_align_all_async).
+  * under a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE (python -m torch.distributed.run --nproc-per-node N
+    bench.py --gpus N ..., or `--launcher spawn`, which starts the N ranks itself BEFORE any GPU call):  one process per
+    GPU, apd_comm_create (ncclCommInitRank) on an id handed over through a rendezvous directory in /tmp, a step =
+    apd_batch_refill + apd_align_all_sharded_async; barriers and the max of the elapsed time go through the library's
+    own all-gather.  Only if the library's communicator cannot be made does this mode fall back to torch.distributed
+    (gloo control plane + nccl all_gather_into_tensor) -- the line then carries "collective_fallback": true and the error.
 
-Prints ONE JSON line on rank 0 (metric: DTW cell-updates/s, whole job), with
-  roofline     -- algorithmic bytes (4*D*(n+m)+4 per ordered pair) / measured kernel time vs 8 TB/s
-  cpu_baseline -- the CPU oracle (a port of the reference's algorithm) timed on a bounded sample
+A step = one full pass of the path over the resident corpus: (features on-device for cfg4 / cfg5,) repack of the
+[sum len][D] frames into the kernels' padded layout, fused-pair DTW over each device's pair tiles, ONE all-gather of
+the packed tile slabs, unpack into the N x N matrix on rank 0's device.  The pair set is fixed as GPUs are added
+(strong scaling).  Timed region: K steps between two fences (every device synchronised, all ranks at a barrier), wall
+clock of the slowest rank.
+
+Prints ONE JSON line (rank 0): metric DTW cell-updates/s (whole job), with
+  roofline      -- algorithmic bytes (4*D*(n+m)+4 per ordered pair) / measured kernel time vs 8 TB/s
+  cpu_baseline  -- the CPU oracle (a port of the reference's algorithm) timed on a bounded sample
+  parity_census -- default distance form vs the bit-exact strict mode over EVERY matrix entry (outside the timed region)
+  secondary     -- cfg2 and cfg1 measured in the same run (N = 1, default workload only)
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -70,6 +78,7 @@ WORKLOADS["full8"] = dict(n_seq=96, length=3000, jitter=1000, dim=10, pct=1.0,
 WORKLOADS["full6"] = dict(n_seq=256, length=600, dim=13, pct=1.0,
                           desc="256 seq len~600 D=13, full DTW (the reference's shipped warping_band_percentage = 1.0 on long slices; not a BASELINE config)")
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK = 1024 * 32 * 2.4e9   # lane-instr/s: 1024 SIMDs x 32 lanes x 2.4 GHz (gfx950 SIMDs are 32 lanes wide: 157.3 TFLOP/s f32 / 2)
 
 
 def parse():
@@ -84,9 +93,16 @@ def parse():
     ap.add_argument("--distance", default="hybrid", choices=["hybrid", "exact", "strict"], help="local-distance form (apd_set_distance_mode); strict = the reference's arithmetic, bit-identical")
     ap.add_argument("--tau", type=float, default=0.0, help="hybrid recomputation threshold (0 = library default 1/64)")
     ap.add_argument("--cluster", action="store_true", help="also time percentile + UPGMA (rank 0, outside the timed region)")
+    ap.add_argument("--launcher", default="auto", choices=["auto", "inprocess", "spawn", "torchrun"],
+                    help="auto: one process per GPU if RANK / WORLD_SIZE are set (torchrun), else ONE process driving --gpus devices "
+                         "through apd_multi; spawn: start the --gpus ranks from here (before any GPU call)")
     ap.add_argument("--backend", default="apd", choices=["apd", "nccl", "gloo"],
-                    help="data-path collective: apd = the library's own RCCL communicator (default); nccl = torch.distributed's; "
-                         "gloo (staged through host memory) only to rehearse N>1 on a box with fewer GPUs")
+                    help="process-per-GPU mode only.  apd = the library's own RCCL communicator (default); nccl = force the torch.distributed "
+                         "fallback; gloo (staged through host memory) only to rehearse N>1 on a box with fewer GPUs")
+    ap.add_argument("--census", default="auto", choices=["auto", "on", "off"],
+                    help="full-matrix parity census against the bit-exact strict mode after timing (auto: when it costs < ~10 s)")
+    ap.add_argument("--secondary", default="auto", choices=["auto", "on", "off"],
+                    help="also measure cfg2 and cfg1 in this run (auto: N = 1 and the default cfg3 workload)")
     return ap.parse_args()
 
 
@@ -134,193 +150,428 @@ def cpu_baseline(frames, offsets, wl, seconds):
     }
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (see the docstring)")
-        args.gpus = world
+# ------------------------------------------------------------------------------------------------- synthetic inputs
 
-    import torch
-    import torch.distributed as dist
-    from audio_pattern_discovery_amd import _lib, synth
-    from audio_pattern_discovery_amd.alignments import align_work
-
-    dev_index = int(os.environ.get("APD_FORCE_DEVICE", local_rank))      # rehearsal: several ranks on one GPU
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    nccl_group = None
-    if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)       # control plane only
-        if args.backend == "nccl":
-            nccl_group = dist.new_group(backend="nccl", device_id=dev)
-
-    wl = WORKLOADS[args.workload]
+def make_inputs(name):
+    """Host-side synthetic inputs of a workload: frames or audio, offsets, encoder weights."""
+    from audio_pattern_discovery_amd import synth
+    wl = WORKLOADS[name]
     n, dim = wl["n_seq"], wl["dim"]
     src_dim = wl.get("encode_from", dim)
-    audio = None
+    inp = dict(wl=wl, name=name, n=n, dim=dim, src_dim=src_dim, audio=None, frames=None, enc_w=None, enc_b=None, s_off=None)
     if wl.get("audio"):
-        # synthetic recordings; the frames the CPU legs use come from the oracle's cepstrum of the same audio
-        from oracle import binding as _orc
         rng_a = np.random.default_rng(0xA0D10)
         n_samp = 256 + 128 * wl["length"]
         base = [synth.make_audio(n_samp, seed=1000 + k) for k in range(16)]
-        audio = [np.clip(base[k % 16].astype(np.int32) + rng_a.integers(-200 * min(k // 16, 40), 200 * min(k // 16, 40) + 1, n_samp, dtype=np.int16),
-                         -32768, 32767).astype(np.int16) for k in range(n)]
-    frames, offsets = (None, None) if audio is not None else synth.make_sequences(n, wl["length"], src_dim, seed=0xA9D0 + sum(map(ord, args.workload)) % 97, jitter=wl.get("jitter"))
-    if audio is not None:
-        s_off = np.concatenate([[0], np.cumsum([len(a) for a in audio])]).astype(np.uint64)
+        inp["audio"] = [np.clip(base[k % 16].astype(np.int32) + rng_a.integers(-200 * min(k // 16, 40), 200 * min(k // 16, 40) + 1, n_samp, dtype=np.int16),
+                                -32768, 32767).astype(np.int16) for k in range(n)]
+        inp["s_off"] = np.concatenate([[0], np.cumsum([len(a) for a in inp["audio"]])]).astype(np.uint64)
         offsets = np.zeros(n + 1, dtype=np.uint64)
-        offsets[1:] = np.cumsum([(len(a) - 256 + 127) // 128 for a in audio])
-    enc_w = enc_b = None
+        offsets[1:] = np.cumsum([(len(a) - 256 + 127) // 128 for a in inp["audio"]])
+    else:
+        inp["frames"], offsets = synth.make_sequences(n, wl["length"], src_dim, seed=0xA9D0 + sum(map(ord, name)) % 97, jitter=wl.get("jitter"))
+    inp["offsets"] = np.ascontiguousarray(offsets, dtype=np.uint64)
     if src_dim != dim:                                               # Mat::seeded-scale random encoder (numerics.rs:178-186)
         rng = np.random.default_rng(0xE1C)
-        enc_w = ((rng.random((src_dim, dim)) - 0.5) / dim).astype(np.float32)
-        enc_b = ((rng.random(dim) - 0.5) / dim).astype(np.float32)
+        inp["enc_w"] = ((rng.random((src_dim, dim)) - 0.5) / dim).astype(np.float32)
+        inp["enc_b"] = ((rng.random(dim) - 0.5) / dim).astype(np.float32)
+    return inp
+
+
+class DeviceInputs:
+    """One device's resident inputs (HBM, through apd_device_alloc) and its feature stage: audio -> cepstra (cfg5),
+    13-dim frames -> embeddings (cfg4), or the frames as they are."""
+
+    def __init__(self, ctx, inp):
+        from audio_pattern_discovery_amd import _lib
+        self._lib, self.L = _lib, _lib.lib()
+        self.ctx, self.inp = ctx, inp
+        total = int(inp["offsets"][-1])
+        self.total = total
+        if inp["audio"] is not None:
+            self.d_audio = ctx.upload(np.concatenate(inp["audio"]))
+            self.d_src = ctx.alloc(total * inp["src_dim"] * 4)
+            self.f_off = np.zeros(inp["n"] + 1, dtype=np.uint64)
+            self.nb = C.c_uint32(0)
+        else:
+            self.d_audio = None
+            self.d_src = ctx.upload(inp["frames"])
+        self.d_frames = self.d_src if inp["enc_w"] is None else ctx.alloc(total * inp["dim"] * 4)
+
+    def features(self):
+        inp, L, ctx = self.inp, self.L, self.ctx
+        f32p, u64p = C.POINTER(C.c_float), C.POINTER(C.c_uint64)
+        if self.d_audio is not None:                                 # NDSequence::new on the whole corpus, in HBM
+            self._lib.check(L.apd_cepstrum_batch(ctx.handle, self.d_audio.at(), inp["s_off"].ctypes.data_as(u64p), inp["n"], 256, 128, 18, 1,
+                                                 self.d_src.at(), self.f_off.ctypes.data_as(u64p), C.byref(self.nb)), ctx.handle)
+        if inp["enc_w"] is not None:                                 # NDSequence::encoded on the whole corpus, in HBM
+            self._lib.check(L.apd_encode(ctx.handle, self.d_src.at(), self.total, inp["src_dim"], inp["enc_w"].ctypes.data_as(f32p),
+                                         inp["enc_b"].ctypes.data_as(f32p), inp["dim"], 1, self.d_frames.at()), ctx.handle)
+
+
+def oracle_features(inp, seqs=None):
+    """Host frames the CPU legs align: the oracle's encoder output for cfg4-like workloads; for audio workloads the oracle's
+    cepstra of the recordings in `seqs` only (returns (frames, offsets, remap))."""
+    from oracle import binding as oracle
+    if inp["audio"] is not None:
+        need = sorted(set(seqs))
+        remap = {s_: k for k, s_ in enumerate(need)}
+        feats = [oracle.cepstrum(inp["audio"][s_], 256, 128, 18) for s_ in need]
+        return np.concatenate(feats), np.concatenate([[0], np.cumsum([len(f) for f in feats])]).astype(np.uint64), remap
+    frames = inp["frames"] if inp["enc_w"] is None else oracle.encode(inp["frames"], inp["enc_w"], inp["enc_b"])
+    return frames, inp["offsets"], None
+
+
+def verify_sample(inp, result, k, seed=7):
+    """max relative error of k random entries of `result` against the CPU oracle."""
+    from oracle import binding as oracle
+    n = inp["n"]
+    rng = np.random.default_rng(seed)
+    pi = rng.integers(0, n, k).astype(np.uint32)
+    pj = (pi + 1 + rng.integers(0, n - 1, k)).astype(np.uint32) % n
+    frames, offsets, remap = oracle_features(inp, pi.tolist() + pj.tolist())
+    qi, qj = (pi, pj) if remap is None else (np.array([remap[v] for v in pi.tolist()], np.uint32), np.array([remap[v] for v in pj.tolist()], np.uint32))
+    want, _ = oracle.align_sample(frames, offsets, qi, qj, inp["wl"]["pct"], workers=host_threads())
+    return float(np.max(np.abs(result[pi, pj] - want) / np.maximum(np.abs(want), 1e-30)))
+
+
+def census(default, strict):
+    """Default-mode matrix against the strict-mode matrix (bit-identical to the CPU arithmetic) over EVERY entry."""
+    fin_d, fin_s = np.isfinite(default), np.isfinite(strict)
+    both = fin_d & fin_s & (strict != 0)
+    rel = np.abs(default[both] - strict[both]) / np.abs(strict[both])
+    over = rel > 1e-4
+    out = {"entries": int(default.size), "max_rel": float(rel.max()) if rel.size else 0.0, "over_1e-4": int(over.sum()),
+           "nonfinite_pattern_equal": bool(np.array_equal(fin_d, fin_s) and np.array_equal(np.isnan(default), np.isnan(strict))
+                                           and np.array_equal(default[~fin_d & ~np.isnan(default)], strict[~fin_s & ~np.isnan(strict)])),
+           "zero_pattern_equal": bool(np.array_equal(default == 0, strict == 0)),
+           "bitwise_equal": int((default.view(np.uint32) == strict.view(np.uint32)).sum()),
+           "reference": "apd_set_distance_mode(2): operation-for-operation arithmetic of numerics.rs:114-120 / alignments.rs:129-160, "
+                        "bit-identical to the CPU oracle (tests/test_gpu_fuzz.py); oracle-anchored by max_rel_err_vs_oracle on the sampled entries"}
+    if over.any():
+        flat = int(np.flatnonzero(both)[int(np.argmax(rel))])
+        out["worst_entry"] = [flat // default.shape[1], flat % default.shape[1]]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- control planes
+
+class FileRendezvous:
+    """Hands small blobs between the ranks of one node through a directory in /tmp (no torch, no sockets): named by the
+    launcher's port and the identity of the common parent process, so concurrent or stale runs cannot meet."""
+
+    def __init__(self, rank, world):
+        ppid = os.getppid()
+        try:
+            start = open("/proc/%d/stat" % ppid).read().rsplit(")", 1)[1].split()[19]
+        except (OSError, IndexError):
+            start = "0"
+        tag = "%s_%s_%d_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), ppid, start)
+        self.dir = os.path.join(os.environ.get("APD_RDZV_DIR", "/tmp"), "apd_bench_rdzv_" + "".join(c if c.isalnum() or c in "_-" else "_" for c in tag))
+        self.rank, self.world = rank, world
+        os.makedirs(self.dir, exist_ok=True)
+
+    def put(self, name, blob):
+        tmp = os.path.join(self.dir, ".%s.%d" % (name, self.rank))
+        with open(tmp, "wb") as f:
+            f.write(blob)
+        os.replace(tmp, os.path.join(self.dir, name))
+
+    def get(self, name, timeout=300.0):
+        path, t0 = os.path.join(self.dir, name), time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > timeout:
+                raise TimeoutError("rendezvous: %s never appeared in %s" % (name, self.dir))
+            time.sleep(0.01)
+        return open(path, "rb").read()
+
+    def gather_status(self, text, tag="status", timeout=300.0):
+        """Every rank posts a line; returns all of them in rank order (a barrier on the host side)."""
+        self.put("%s.%d" % (tag, self.rank), text.encode())
+        return [self.get("%s.%d" % (tag, r), timeout).decode() for r in range(self.world)]
+
+    def finish(self):
+        """Every rank has passed its last use of the directory: rank 0 waits for all of them, then removes it."""
+        self.put("done.%d" % self.rank, b"")
+        if self.rank == 0:
+            import shutil
+            for r in range(self.world):
+                self.get("done.%d" % r)
+            shutil.rmtree(self.dir, ignore_errors=True)
+
+
+class DeviceView:
+    """A library-owned device buffer seen through __cuda_array_interface__ (torch fallback path only)."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+# ------------------------------------------------------------------------------------------------- secondary workloads
+
+def measure_secondary(ctx, name, steps=5):
+    """A smaller BASELINE configuration measured on the same context in the same run: resident inputs, `steps` timed
+    steps (repack + alignment + unpack), kernel time from HIP events, parity against the oracle on sampled entries."""
+    from audio_pattern_discovery_amd import _lib
+    from audio_pattern_discovery_amd.alignments import align_work
     L = _lib.lib()
+    inp = make_inputs(name)
+    wl, n, dim = inp["wl"], inp["n"], inp["dim"]
+    cfg = _lib.AlignConfig(wl["pct"], 1.0, 1.0, 1.0)
+    pairs, cells, alg_bytes = align_work(inp["offsets"], dim, cfg, 0, 1)
+    dev = DeviceInputs(ctx, inp)
+    d_out = ctx.alloc(n * n * 4)
+    batch = C.c_void_p()
+    u64p = C.POINTER(C.c_uint64)
+    _lib.check(L.apd_batch_create(ctx.handle, dev.d_frames.at(), inp["offsets"].ctypes.data_as(u64p), n, dim, 1, C.byref(batch)), ctx.handle)
+
+    def step():
+        _lib.check(L.apd_batch_refill(ctx.handle, batch, dev.d_frames.at(), 1), ctx.handle)
+        _lib.check(L.apd_align_all_device_async(ctx.handle, batch, C.byref(cfg), d_out.at()), ctx.handle)
+
+    step()
+    ctx.synchronize()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+        kernel_ms.append(ctx.last_kernel_ms())
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    result = d_out.to_numpy(np.float32).reshape(n, n)
+    L.apd_batch_destroy(batch)
+    k_ms = float(np.mean(kernel_ms))
+    err = verify_sample(inp, result, 64)
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    return {"workload": "%s: %s" % (name, wl["desc"]), "steps": steps, "ms_per_step": elapsed / steps * 1e3, "value": cells * steps / elapsed,
+            "unit": "cell-updates/s", "kernel_ms": k_ms, "kernel_cells_per_s": cells / (k_ms * 1e-3), "alg_bytes_per_launch": alg_bytes,
+            "roofline_achieved_GBs": achieved, "roofline_frac": achieved / HBM_PEAK_GBS, "max_rel_err_vs_oracle": err, "parity_ok": bool(err <= 1e-4)}
+
+
+# ------------------------------------------------------------------------------------------------- launch modes
+
+def spawn_ranks(args):
+    """--launcher spawn: start the N ranks from here, BEFORE this process makes any GPU call; forward rank 0's line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = [a for a in sys.argv[1:]]
+    for k, a in enumerate(argv):
+        if a == "--launcher":
+            argv[k + 1] = "auto"
+        elif a.startswith("--launcher="):
+            argv[k] = "--launcher=auto"
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    raise SystemExit(rc)
+
+
+def main():
+    args = parse()
+    env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    under_launcher = "RANK" in os.environ and env_world >= 1
+    if args.launcher == "spawn" and not under_launcher and args.gpus > 1:
+        spawn_ranks(args)
+    if args.launcher == "torchrun" and not under_launcher and args.gpus > 1:
+        raise SystemExit("--launcher torchrun: start me with `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % args.gpus)
+    ranks_mode = under_launcher and env_world > 1 and args.launcher != "inprocess"
+    rank = int(os.environ.get("RANK", "0")) if ranks_mode else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if ranks_mode else 0
+    world = env_world if ranks_mode else max(args.gpus, 1)
+    multi_mode = (not ranks_mode) and world > 1
+    args.gpus = world
+
+    from audio_pattern_discovery_amd import _lib, sharding
+    from audio_pattern_discovery_amd.alignments import align_work
+    L = _lib.lib()
+    f32p, u64p = C.POINTER(C.c_float), C.POINTER(C.c_uint64)
+
+    inp = make_inputs(args.workload)
+    wl, n, dim = inp["wl"], inp["n"], inp["dim"]
+    offsets = inp["offsets"]
     cfg = _lib.AlignConfig(wl["pct"], 1.0, 1.0, 1.0)
     pairs_all, cells_all, bytes_all = align_work(offsets, dim, cfg, 0, 1)
     pairs_r, cells_r, bytes_r = align_work(offsets, dim, cfg, rank, world)
 
-    ctx = _lib.Context(dev_index, stream=torch.cuda.current_stream().cuda_stream)
-    ctx.selftest()
-    ctx.set_variant(args.variant)
-    ctx.set_distance_mode(args.distance, args.tau)
-    ctx.set_timing(True)
-    total_frames = int(offsets[-1])
-    if audio is not None:
-        d_audio = torch.from_numpy(np.concatenate(audio)).to(dev)    # inputs resident in HBM
-        d_src = torch.empty(total_frames * dim, dtype=torch.float32, device=dev)
-        f_off = np.zeros(n + 1, dtype=np.uint64)
-        nb = C.c_uint32(0)
+    # ---- devices, contexts, communicator --------------------------------------------------------------------------
+    multi = comm = rdzv = None
+    collective, collective_fallback, collective_error, ranks_seen = "none (1 rank)", False, None, 1
+    dist = torch = nccl_group = None
+    if multi_mode:
+        first = int(os.environ.get("APD_FIRST_DEVICE", "0"))
+        multi = sharding.Multi(list(range(first, first + world)))
+        ctxs = multi.contexts
+        collective, ranks_seen = "apd_multi: " + multi.collective(), multi.ranks_seen()
+        collective_fallback = multi.collective().startswith("peer-copy")
+        if collective_fallback:
+            collective_error = multi.collective()
+            sys.stderr.write("[bench] %s\n" % collective_error)
     else:
-        d_src = torch.from_numpy(frames).to(dev)                     # inputs resident in HBM
-    d_frames = d_src if enc_w is None else torch.empty(total_frames * dim, dtype=torch.float32, device=dev)
-    f32p = C.POINTER(C.c_float)
-    off_c = np.ascontiguousarray(offsets, dtype=np.uint64)
+        dev_index = int(os.environ.get("APD_FORCE_DEVICE", local_rank))  # rehearsal: several ranks on one GPU
+        ctxs = [_lib.Context(dev_index)]
+    ctx = ctxs[0]
+    for c in ctxs:
+        c.selftest()
+        c.set_variant(args.variant)
+        c.set_distance_mode(args.distance, args.tau)
+        c.set_timing(True)
+    devs = [DeviceInputs(c, inp) for c in ctxs]                      # inputs resident in HBM (every device holds the corpus)
+    d_out = ctx.alloc(n * n * 4)
     slab_floats = int(L.apd_slab_floats(n, world))
-    d_out = torch.empty(n * n, dtype=torch.float32, device=dev)
-    kernel_ms = []
-    # the library-owned communicator (one process per GPU: rank 0 makes the id, the control plane hands it out)
-    comm, ranks_seen, collective = None, 1, "none (1 rank)"
-    if world > 1 and args.backend == "apd":
-        from audio_pattern_discovery_amd import sharding
-        box = [sharding.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        ok = 1
-        try:
-            comm = sharding.Comm(ctx, box[0], rank, world)
-            ranks_seen = comm.count()
-            # one small all-gather now: RCCL sets its channels up on first use, which must not land in a timed step (--warmup 0)
-            warm_src = torch.full((256,), float(rank), dtype=torch.float32, device=dev)
-            warm_dst = torch.empty(256 * world, dtype=torch.float32, device=dev)
-            _lib.check(L.apd_all_gather_async(ctx.handle, comm.handle, C.c_void_p(warm_src.data_ptr()), C.c_void_p(warm_dst.data_ptr()), 256),
-                       ctx.handle)
-            ctx.synchronize()
-            if not torch.equal(warm_dst.view(world, 256)[:, 0].cpu(), torch.arange(world, dtype=torch.float32)):
-                raise RuntimeError("all-gather returned the slabs out of rank order")
-        except Exception as exc:                                         # noqa: BLE001 -- any failure: agree on the fallback
-            sys.stderr.write("[bench] rank %d: apd_comm_create failed (%s); falling back to torch.distributed nccl\n" % (rank, exc))
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            collective = "apd_comm: library-owned RCCL communicator, ncclAllGather inside apd_align_all_sharded_async"
+
+    if ranks_mode:
+        rdzv = FileRendezvous(rank, world)
+        err = ""
+        if args.backend == "apd":
+            try:
+                if rank == 0:
+                    rdzv.put("id", sharding.Comm.unique_id())
+                comm = sharding.Comm(ctx, rdzv.get("id"), rank, world)   # ncclCommInitRank: collective over the ranks
+                ranks_seen = comm.count()
+                # one small all-gather now: RCCL sets its channels up on first use, which must not land in a timed step (--warmup 0)
+                warm_src, warm_dst = ctx.upload(np.full(256, float(rank), np.float32)), ctx.alloc(256 * world * 4)
+                _lib.check(L.apd_all_gather_async(ctx.handle, comm.handle, warm_src.at(), warm_dst.at(), 256), ctx.handle)
+                ctx.synchronize()
+                if not np.array_equal(warm_dst.to_numpy(np.float32).reshape(world, 256)[:, 0], np.arange(world, dtype=np.float32)):
+                    raise RuntimeError("all-gather returned the slabs out of rank order")
+            except Exception as exc:                                     # noqa: BLE001 -- any failure: agree on the fallback
+                err = "rank %d: %s: %s" % (rank, type(exc).__name__, exc)
+                sys.stderr.write("[bench] library communicator failed (%s); falling back to torch.distributed\n" % err)
         else:
+            err = "forced by --backend %s" % args.backend
+        status = rdzv.gather_status(err)
+        if any(status):
+            collective_fallback = args.backend == "apd"
+            collective_error = "; ".join(s for s in status if s)
             if comm is not None:
                 comm.close()
                 comm = None
-            args.backend = "nccl"
-            nccl_group = dist.new_group(backend="nccl", device_id=dev)
-    if world > 1 and args.backend == "nccl":
-        collective = "torch.distributed all_gather_into_tensor (nccl = RCCL)"
-        ranks_seen = dist.get_world_size(nccl_group)
-    elif world > 1 and args.backend == "gloo":
-        collective = "gloo through host memory (rehearsal only)"
-    if comm is None:
-        d_slab = torch.zeros(slab_floats, dtype=torch.float32, device=dev)
-        d_gathered = torch.zeros(slab_floats * world, dtype=torch.float32, device=dev) if world > 1 else d_slab
-    # AlignmentWorkers::new once; every step refills the resident copy from the features it just made (same lengths), so the
-    # device buffers and the tile plans are made once, not per step
+            import torch                                                 # fallback only: control plane + collective from torch
+            import torch.distributed as dist
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            if args.backend != "gloo":
+                torch.cuda.set_device(dev_index)
+                nccl_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+                collective, ranks_seen = "torch.distributed all_gather_into_tensor (nccl = RCCL)", dist.get_world_size(nccl_group)
+            else:
+                collective = "gloo through host memory (rehearsal only)"
+            d_slab, d_gathered = ctx.alloc(slab_floats * 4), ctx.alloc(slab_floats * world * 4)
+            if nccl_group is not None:
+                t_slab = torch.as_tensor(DeviceView(d_slab.ptr, slab_floats), device="cuda")
+                t_gathered = torch.as_tensor(DeviceView(d_gathered.ptr, slab_floats * world), device="cuda")
+        else:
+            collective = "apd_comm: library-owned RCCL communicator (ncclCommInitRank), ncclAllGather inside apd_align_all_sharded_async"
+        gather_one, gather_src = (ctx.alloc(4 * world), ctx.alloc(4)) if comm is not None else (None, None)
+
+    def all_ranks(value):
+        """Every rank's float, in rank order (also a barrier).  Library all-gather; torch only in the fallback."""
+        if not ranks_mode:
+            return [value]
+        if comm is not None:
+            gather_src.copy_from(np.array([value], np.float32))
+            _lib.check(L.apd_all_gather_async(ctx.handle, comm.handle, gather_src.at(), gather_one.at(), 1), ctx.handle)
+            ctx.synchronize()
+            return gather_one.to_numpy(np.float32).astype(np.float64).tolist()
+        t = torch.zeros(world, dtype=torch.float64)
+        t[rank] = value
+        dist.all_reduce(t)
+        return t.tolist()
+
+    # ---- the step ---------------------------------------------------------------------------------------------------
     batch = C.c_void_p()
+    mbatch = None
+
+    def make_batch():
+        nonlocal mbatch
+        if multi_mode:
+            mbatch = multi.batch(offsets, dim, d_frames=[d.d_frames.ptr for d in devs])
+        else:
+            _lib.check(L.apd_batch_create(ctx.handle, devs[0].d_frames.at(), offsets.ctypes.data_as(u64p), n, dim, 1, C.byref(batch)), ctx.handle)
 
     def step():
-        if audio is not None:                                        # NDSequence::new on the whole corpus, in HBM
-            _lib.check(L.apd_cepstrum_batch(ctx.handle, C.c_void_p(d_audio.data_ptr()), s_off.ctypes.data_as(C.POINTER(C.c_uint64)), n,
-                                            256, 128, 18, 1, C.c_void_p(d_src.data_ptr()), f_off.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                            C.byref(nb)), ctx.handle)
-        if enc_w is not None:                                        # NDSequence::encoded on the whole corpus, in HBM
-            _lib.check(L.apd_encode(ctx.handle, C.c_void_p(d_src.data_ptr()), total_frames, src_dim, enc_w.ctypes.data_as(f32p),
-                                    enc_b.ctypes.data_as(f32p), dim, 1, C.c_void_p(d_frames.data_ptr())), ctx.handle)
-        if not batch:
-            _lib.check(L.apd_batch_create(ctx.handle, C.c_void_p(d_frames.data_ptr()), off_c.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                          n, dim, 1, C.byref(batch)), ctx.handle)
+        for d in devs:
+            d.features()
+        if multi_mode:
+            if mbatch is None:
+                make_batch()
+            else:
+                mbatch.refill(d_frames=[d.d_frames.ptr for d in devs])
+            multi.align_all_async(mbatch, cfg, d_out.ptr)
+            return
+        if not batch:                                                # AlignmentWorkers::new once; later steps refill the resident copy
+            make_batch()
         else:
-            _lib.check(L.apd_batch_refill(ctx.handle, batch, C.c_void_p(d_frames.data_ptr()), 1), ctx.handle)
+            _lib.check(L.apd_batch_refill(ctx.handle, batch, devs[0].d_frames.at(), 1), ctx.handle)
         if comm is not None or world == 1:
             # tiles of this rank + the one ncclAllGather (RCCL over xGMI) + unpack, all inside the library
-            _lib.check(L.apd_align_all_sharded_async(ctx.handle, comm.handle if comm is not None else None, batch, C.byref(cfg),
-                                                     C.c_void_p(d_out.data_ptr())), ctx.handle)
+            _lib.check(L.apd_align_all_sharded_async(ctx.handle, comm.handle if comm is not None else None, batch, C.byref(cfg), d_out.at()), ctx.handle)
             return
-        _lib.check(L.apd_align_tiles_async(ctx.handle, batch, C.byref(cfg), rank, world, C.c_void_p(d_slab.data_ptr())),
-                   ctx.handle)
-        if args.backend == "nccl":
-            dist.all_gather_into_tensor(d_gathered, d_slab, group=nccl_group)
+        _lib.check(L.apd_align_tiles_async(ctx.handle, batch, C.byref(cfg), rank, world, d_slab.at()), ctx.handle)   # torch fallback
+        ctx.synchronize()
+        if nccl_group is not None:
+            dist.all_gather_into_tensor(t_gathered, t_slab, group=nccl_group)
+            torch.cuda.synchronize()
         else:
             host = torch.empty(slab_floats * world, dtype=torch.float32)
-            dist.all_gather_into_tensor(host, d_slab.cpu())          # rehearsal path only
-            d_gathered.copy_(host)
-        _lib.check(L.apd_unpack_tiles_async(ctx.handle, batch, world, C.c_void_p(d_gathered.data_ptr()),
-                                            C.c_void_p(d_out.data_ptr())), ctx.handle)
+            dist.all_gather_into_tensor(host, torch.from_numpy(d_slab.to_numpy(np.float32)))
+            d_gathered.copy_from(host.numpy())
+        _lib.check(L.apd_unpack_tiles_async(ctx.handle, batch, world, d_gathered.at(), d_out.at()), ctx.handle)
 
     def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        if multi_mode:
+            multi.synchronize()                                      # every device; raises APD_ERR_INCOMPLETE if an unpack met an unwritten score
+            return
+        ctx.synchronize()
+        if ranks_mode:
+            all_ranks(0.0)                                           # barrier
+            ctx.synchronize()
 
     for _ in range(max(args.warmup, 0)):
         step()
-    if not batch:                                                    # --warmup 0: AlignmentWorkers::new is not part of a step
-        _lib.check(L.apd_batch_create(ctx.handle, C.c_void_p(d_frames.data_ptr()), off_c.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                      n, dim, 1, C.byref(batch)), ctx.handle)
+    if not batch and mbatch is None:                                 # --warmup 0: AlignmentWorkers::new is not part of a step
+        for d in devs:
+            d.features()
+        make_batch()
+    kernel_ms = []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        ms = ctx.last_kernel_ms()                                    # syncs on the kernel's end event only
-        kernel_ms.append(ms)
+        kernel_ms.append(ctx.last_kernel_ms())                       # syncs on the kernel's end event only
     fence()
     elapsed = time.perf_counter() - t0
-    ctx.synchronize()                                                # raises APD_ERR_INCOMPLETE if any unpack met an unwritten score
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max(all_ranks(elapsed))
+
+    result = d_out.to_numpy(np.float32).reshape(n, n) if rank == 0 else None
+    # ---- parity census: the default distance form against strict mode (bit-identical to the CPU arithmetic) over EVERY entry,
+    # on the same resident batch, after the timed region; every rank takes part (the strict run is sharded like a step)
+    strict, census_seconds = None, 0.0
+    want_census = args.census == "on" or (args.census == "auto" and args.distance != "strict" and cells_all <= 3e12)
+    if want_census and (multi_mode or comm is not None or world == 1):
+        t0 = time.perf_counter()
+        for c in ctxs:
+            c.set_distance_mode("strict")
+        if multi_mode:
+            multi.align_all_async(mbatch, cfg, d_out.ptr)
+        else:
+            _lib.check(L.apd_align_all_sharded_async(ctx.handle, comm.handle if comm is not None else None, batch, C.byref(cfg), d_out.at()), ctx.handle)
+        fence()
+        for c in ctxs:
+            c.set_distance_mode(args.distance, args.tau)
+        if rank == 0:
+            strict = d_out.to_numpy(np.float32).reshape(n, n)
+            d_out.copy_from(result.ravel())                          # leave the default-mode matrix resident (the UPGMA leg reads it)
+        census_seconds = time.perf_counter() - t0
 
     if rank == 0:
-        result = d_out.cpu().numpy().reshape(n, n)
-        verify = None
-        if args.verify > 0:
-            from oracle import binding as oracle
-            rng = np.random.default_rng(7)
-            pi = rng.integers(0, n, args.verify).astype(np.uint32)
-            pj = (pi + 1 + rng.integers(0, n - 1, args.verify)).astype(np.uint32) % n
-            if audio is not None:                                    # oracle cepstrum of the sampled recordings only
-                need = sorted(set(pi.tolist()) | set(pj.tolist()))
-                remap = {s_: k for k, s_ in enumerate(need)}
-                feats = [oracle.cepstrum(audio[s_], 256, 128, 18) for s_ in need]
-                ref_frames = np.concatenate(feats)
-                ref_off = np.concatenate([[0], np.cumsum([len(f) for f in feats])]).astype(np.uint64)
-                want, _ = oracle.align_sample(ref_frames, ref_off, np.array([remap[v] for v in pi.tolist()], np.uint32),
-                                              np.array([remap[v] for v in pj.tolist()], np.uint32), wl["pct"], workers=host_threads())
-            else:
-                ref_frames = frames if enc_w is None else oracle.encode(frames, enc_w, enc_b)
-                want, _ = oracle.align_sample(ref_frames, offsets, pi, pj, wl["pct"], workers=host_threads())
-            verify = float(np.max(np.abs(result[pi, pj] - want) / np.maximum(np.abs(want), 1e-30)))
+        verify = verify_sample(inp, result, args.verify) if args.verify > 0 else None
         traffic = valu_insts = None
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(args.workload)
@@ -331,6 +582,8 @@ def main():
             pass
         k_ms = float(np.mean(kernel_ms))
         achieved = bytes_r / (k_ms * 1e-3) / 1e9
+        mode = ("one process driving %d devices (apd_multi)" % world if multi_mode else
+                "one process per GPU (%s)" % ("torchrun / env ranks" if ranks_mode else "single device"))
         line = {
             "metric": "DTW cell-updates/sec (whole node)", "value": cells_all * args.steps / elapsed,
             "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -339,7 +592,9 @@ def main():
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "n_seq": n, "nominal_len": wl["length"],
                        "dim": dim, "warping_band_percentage": wl["pct"], "ordered_pairs": pairs_all,
                        "cells_per_step": cells_all, "sharding": "pair tiles 16x16, cyclic over %d ranks, 1 all-gather" % world,
-                       "collective": collective, "ranks_seen": ranks_seen,
+                       "launch": mode, "collective": collective, "collective_fallback": collective_fallback,
+                       "collective_error": collective_error, "ranks_seen": ranks_seen,
+                       "runtime": _lib.runtime_info(), "torch_imported": "torch" in sys.modules,
                        "kernel_variant": args.variant, "distance_form": args.distance},
             "wall_clock_matrix_s": elapsed / args.steps,
             "pairs_per_s": pairs_all * args.steps / elapsed,
@@ -354,58 +609,67 @@ def main():
                          "kernel_ms": k_ms, "alg_bytes_per_launch": bytes_r,
                          "kernel_cells_per_s": cells_r / (k_ms * 1e-3)},
             # the kernel is VALU-bound, so the HBM fraction above is reported next to the vector-issue figure:
-            # lane-instructions per cell from the SQ_INSTS_VALU counter of this workload, times the live cell rate, over the
-            # 7.86e13 lane-instr/s of 1024 SIMDs x 32 lanes x 2.4 GHz (gfx950 SIMDs are 32 lanes wide: 157.3 TFLOP/s f32 / 2)
+            # lane-instructions per cell from the SQ_INSTS_VALU counter of this workload, times the live cell rate, over VALU_PEAK
             "valu": None if not valu_insts else {
                 "lane_instr_per_cell": valu_insts * 64.0 / cells_r,
                 "lane_instr_per_s": valu_insts * 64.0 / (k_ms * 1e-3),
-                "peak_lane_instr_per_s": 1024 * 32 * 2.4e9,
-                "frac": valu_insts * 64.0 / (k_ms * 1e-3) / (1024 * 32 * 2.4e9),
+                "peak_lane_instr_per_s": VALU_PEAK,
+                "frac": valu_insts * 64.0 / (k_ms * 1e-3) / VALU_PEAK,
                 "source": "profiles/hbm_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU of this command, committed; not re-measured in this run)"},
-            "max_rel_err_vs_oracle": verify, "parity_ok": (verify is None) or bool(verify <= (1e-3 if audio is not None else 1e-4)),
+            "max_rel_err_vs_oracle": verify, "parity_ok": (verify is None) or bool(verify <= (1e-3 if inp["audio"] is not None else 1e-4)),
         }
-        if frames is not None and enc_w is None and world == 1:
+        if strict is not None:
+            line["parity_census"] = census(result, strict)
+            line["parity_census"]["seconds"] = census_seconds
+            line["parity_census"]["strict_max_rel_err_vs_oracle"] = verify_sample(inp, strict, min(args.verify, 32), seed=11) if args.verify > 0 else None
+            line["parity_ok"] = bool(line["parity_ok"] and line["parity_census"]["over_1e-4"] == 0 and
+                                     line["parity_census"]["nonfinite_pattern_equal"] and line["parity_census"]["zero_pattern_equal"])
+        if inp["frames"] is not None and inp["enc_w"] is None and world == 1:
             # the host-buffer entry of the boundary (AlignmentWorkers::new + align_all on host Vec<f32>s): H2D of the frames,
             # repack, kernel, unpack, D2H of the matrix -- reported beside `value`, never as it
             host_out = np.empty(n * n, dtype=np.float32)
             hb = C.c_void_p()
             t0 = time.perf_counter()
-            _lib.check(L.apd_batch_create(ctx.handle, frames.ctypes.data_as(f32p), off_c.ctypes.data_as(C.POINTER(C.c_uint64)), n, dim, 0,
-                                          C.byref(hb)), ctx.handle)
+            _lib.check(L.apd_batch_create(ctx.handle, inp["frames"].ctypes.data_as(f32p), offsets.ctypes.data_as(u64p), n, dim, 0, C.byref(hb)), ctx.handle)
             _lib.check(L.apd_align_all(ctx.handle, hb, C.byref(cfg), host_out.ctypes.data_as(f32p)), ctx.handle)
             dt = time.perf_counter() - t0
             L.apd_batch_destroy(hb)
             line["pcie_inclusive"] = {"seconds": dt, "value": cells_all / dt, "unit": "cell-updates/s",
-                                      "h2d_bytes": int(frames.nbytes), "d2h_bytes": int(host_out.nbytes),
+                                      "h2d_bytes": int(inp["frames"].nbytes), "d2h_bytes": int(host_out.nbytes),
                                       "bitwise_equal_to_resident_path": bool(np.array_equal(host_out.reshape(n, n), result)),
                                       "note": "apd_batch_create(host frames) + apd_align_all(host out), pageable host memory, one call"}
         if args.cluster:
             ops = (_lib.ClusterOp * n)()
             roots = np.zeros(n, dtype=np.uint32)
             n_ops, n_roots, thr = C.c_uint32(0), C.c_uint32(0), C.c_float(0)
-            torch.cuda.synchronize()
-            cl_ctx = _lib.Context(dev_index)                         # a context with its own stream: the merge loop is replayed as a hipGraph,
-            t0 = time.perf_counter()                                 # which the legacy default stream (torch's current one) cannot capture
-            _lib.check(L.apd_clustering(cl_ctx.handle, C.c_void_p(d_out.data_ptr()), 1, n, 0.05, ops, C.byref(n_ops),
-                                        roots.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n_roots), C.byref(thr)), cl_ctx.handle)
+            t0 = time.perf_counter()
+            _lib.check(L.apd_clustering(ctx.handle, d_out.at(), 1, n, 0.05, ops, C.byref(n_ops),
+                                        roots.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n_roots), C.byref(thr)), ctx.handle)
             line["clustering"] = {"seconds": time.perf_counter() - t0, "merges": int(n_ops.value), "roots": int(n_roots.value),
                                   "threshold": float(thr.value), "percentile": 0.05,
                                   "note": "apd_clustering on the resident matrix: radix-select threshold + UPGMA (clustering.rs:81-110)"}
-        if world == 1 and args.cpu_seconds > 0 and audio is not None:
-            line["cpu_baseline"] = None                              # the CPU legs would need the whole corpus' cepstra on the host
-        elif world == 1 and args.cpu_seconds > 0:
-            from oracle import binding as _o
-            line["cpu_baseline"] = cpu_baseline(frames if enc_w is None else _o.encode(frames, enc_w, enc_b), offsets, wl, args.cpu_seconds)
+        if world == 1 and (args.secondary == "on" or (args.secondary == "auto" and args.workload == "cfg3")):
+            line["secondary"] = {name: measure_secondary(ctx, name) for name in ("cfg2", "cfg1")}
+        if world == 1 and args.cpu_seconds > 0 and inp["audio"] is None:
+            line["cpu_baseline"] = cpu_baseline(oracle_features(inp)[0], offsets, wl, args.cpu_seconds)
         else:
-            line["cpu_baseline"] = None
+            line["cpu_baseline"] = None                              # audio workloads: the CPU legs would need the whole corpus' cepstra on the host
         print(json.dumps(line), flush=True)
+    if ranks_mode:
+        all_ranks(0.0)                                               # nobody tears the communicator down while rank 0 still works
     if batch:
         L.apd_batch_destroy(batch)
+    if mbatch is not None:
+        mbatch.close()
     if comm is not None:
         comm.close()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rdzv is not None:
+        rdzv.finish()
+    if multi is not None:
+        multi.close()
 
 
 if __name__ == "__main__":

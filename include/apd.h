@@ -185,10 +185,63 @@ int apd_align_all_sharded_async(apd_context *ctx, apd_comm *comm, const apd_batc
  * every rank, concatenated in rank order into d_recv (count * world floats), on the context's stream. */
 int apd_all_gather_async(apd_context *ctx, apd_comm *comm, const float *d_send, float *d_recv, uint64_t count);
 /* frames / offsets / out: host memory, as apd_batch_create + apd_align_all take them.  devices: HIP device ordinals.
- * Blocking; starts n_devices - 1 host threads of its own for the uploads and launches (joined before it returns) -- the
- * counterpart of the reference's `alignment_workers` threads, one per GPU. */
+ * Blocking.  ONE-SHOT convenience over the persistent handle below (apd_multi_create + apd_multi_batch_create +
+ * apd_multi_align_all + destroy): it pays communicator setup on every call -- a host that aligns more than once
+ * (main.rs:187-195 in a loop) keeps an apd_multi instead. */
 int apd_align_all_multi(const int *devices, uint32_t n_devices, const float *frames, const uint64_t *offsets, uint32_t n_seq,
                         uint32_t dim, const apd_align_config *cfg, float *out, uint32_t *ranks_seen);
+
+/* ---- (2) as a persistent handle: AlignmentWorkers { data, result } (alignments.rs:11-14) over n_devices GPUs ---------
+ * apd_multi owns, for its whole life: one apd_context per device (own stream), the RCCL communicators of
+ * ncclCommInitAll, one host worker thread per device (the reference's `alignment_workers` threads, alignments.rs:35-41:
+ * here a worker feeds a GPU), the gather workspaces and -- per apd_multi_batch -- one resident copy of the corpus and the
+ * cached tile plans on every device.  Create once, align many: a second apd_multi_align_all pays kernels + one
+ * all-gather + unpack only.
+ * If RCCL cannot make the communicators (or APD_MULTI_COLLECTIVE=peer is set), the handle falls back to gathering the slabs
+ * onto devices[0] with hipMemcpyPeerAsync; apd_multi_collective() says which and carries RCCL's error text.  Results are
+ * the same bits either way (the collective only moves the slabs). */
+typedef struct apd_multi apd_multi;
+typedef struct apd_multi_batch apd_multi_batch;
+int apd_multi_create(const int *devices, uint32_t n_devices, apd_multi **multi);
+int apd_multi_destroy(apd_multi *multi);                     /* also destroys the batches still alive on it */
+uint32_t apd_multi_size(const apd_multi *multi);             /* n_devices */
+int apd_multi_ranks_seen(const apd_multi *multi, uint32_t *ranks);   /* ncclCommCount (n_devices in the peer-copy fallback) */
+const char *apd_multi_collective(const apd_multi *multi);    /* "rccl: ..." or "peer-copy fallback: <why>" */
+const char *apd_multi_last_error(const apd_multi *multi);    /* "device k: <text>" of the last failing call */
+/* Device i's context, owned by the handle (never apd_destroy it): for the per-device settings (apd_set_distance_mode,
+ * apd_set_timing, apd_set_variant), the feature kernels (apd_encode, apd_cepstrum_batch) and buffers on that device. */
+apd_context *apd_multi_context(apd_multi *multi, uint32_t i);
+/* AlignmentWorkers::new (alignments.rs:17-26) on every device.  Either `frames` (host, packed as for apd_batch_create,
+ * uploaded to every device by its worker thread) or `d_frames` (n_devices device pointers, d_frames[i] in device i's
+ * HBM, only read during the call) must be given. */
+int apd_multi_batch_create(apd_multi *multi, const float *frames, const float *const *d_frames, const uint64_t *offsets,
+                           uint32_t n_seq, uint32_t dim, apd_multi_batch **batch);
+int apd_multi_batch_refill(apd_multi *multi, apd_multi_batch *batch, const float *frames, const float *const *d_frames);
+int apd_multi_batch_destroy(apd_multi_batch *batch);
+/* AlignmentWorkers::align_all (alignments.rs:31-67): every device aligns its pair tiles (g = i mod n_devices), ONE grouped
+ * ncclAllGather, unpack on devices[0].  d_out: n_seq*n_seq floats in devices[0]'s HBM (NULL: a buffer owned by the handle,
+ * see apd_multi_result).  Returns when every device's work is ENQUEUED (the workers wait for their repack kernel's
+ * verdict on non-finite frames first: see apd_align_tiles_async); apd_multi_synchronize waits for all devices and
+ * reports APD_ERR_INCOMPLETE like apd_synchronize. */
+int apd_multi_align_all_async(apd_multi *multi, const apd_multi_batch *batch, const apd_align_config *cfg, float *d_out);
+int apd_multi_synchronize(apd_multi *multi);
+/* Device address (devices[0]) of the matrix the last apd_multi_align_all_async(.., d_out = NULL) wrote; NULL if none. */
+const float *apd_multi_result(const apd_multi *multi);
+/* Blocking form: out = n_seq*n_seq floats, host. */
+int apd_multi_align_all(apd_multi *multi, const apd_multi_batch *batch, const apd_align_config *cfg, float *out);
+
+/* ---- device buffers -------------------------------------------------------------------------------------------------
+ * For hosts that keep features or the matrix resident between calls (what a Rust binding wraps in a Drop-ing DeviceVec):
+ * plain hipMalloc / hipFree / hipMemcpy on the context's device, the copies ordered on the context's stream and
+ * complete when the call returns. */
+int apd_device_alloc(apd_context *ctx, uint64_t bytes, void **d_ptr);
+int apd_device_free(apd_context *ctx, void *d_ptr);
+int apd_copy_to_device(apd_context *ctx, void *d_dst, const void *src, uint64_t bytes);
+int apd_copy_to_host(apd_context *ctx, void *dst, const void *d_src, uint64_t bytes);
+int apd_device_fill(apd_context *ctx, void *d_dst, int byte_value, uint64_t bytes);   /* hipMemsetAsync on the stream */
+/* Which HIP and RCCL libraries this process actually mapped for the library's calls (dladdr of hipMalloc /
+ * ncclAllGather) and their versions, as one line of text; returns the length needed (incl. NUL). */
+uint64_t apd_runtime_info(char *out, uint64_t capacity);
 
 /* Host-side views of the same sharding (no GPU needed): the length order (order[p] = sequence at position p), the
  * (tile_a, tile_b) list of a rank over those positions, 2 uint32 per tile, and the scatter of gathered slabs held in

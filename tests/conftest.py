@@ -3,10 +3,9 @@ import sys
 
 import pytest
 
-try:                # torch bundles its own HIP runtime: load it BEFORE libapd_hip.so pulls in /opt/rocm's,
-    import torch    # so that one process never holds two HIP runtimes (only matters for tests using both)
-except Exception:   # pragma: no cover
-    torch = None
+# No torch here: the GPU suite runs on the HIP / RCCL runtime libapd_hip.so is linked against (/opt/rocm), with device
+# buffers from the library itself (apd_device_alloc).  The one test that shares a stream and tensors with torch
+# (tests/test_gpu_runtime.py) does so in a child process, where torch's bundled runtime is loaded first.
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

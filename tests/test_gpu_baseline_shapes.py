@@ -34,7 +34,6 @@ def rel_err(got, want):
 
 
 def test_cfg5_shape_audio_to_matrix_on_device(ctx, oracle, apd):
-    import torch
     L = apd.lib()
     n, n_samp = 256, 256 + 128 * 2048                                   # 262 400 samples -> 2048 frames
     rng = np.random.default_rng(0xC5)
@@ -46,22 +45,41 @@ def test_cfg5_shape_audio_to_matrix_on_device(ctx, oracle, apd):
         audio.append(np.clip(base[k % 16].astype(np.int32) + noise, -32768, 32767).astype(np.int16))
     audio[200] = audio[40].copy()                                        # an exact repeat: both ordered scores exactly 0
     s_off = (np.arange(n + 1, dtype=np.uint64) * n_samp)
-    d_audio = torch.from_numpy(np.concatenate(audio)).cuda()
+    d_audio = ctx.upload(np.concatenate(audio))
     f_off = np.zeros(n + 1, dtype=np.uint64)
     nb = C.c_uint32(0)
-    d_ceps = torch.empty(n * 2048 * 13, dtype=torch.float32, device="cuda")
-    apd.check(L.apd_cepstrum_batch(ctx.handle, C.c_void_p(d_audio.data_ptr()), s_off.ctypes.data_as(u64p), n, 256, 128, 18, 1,
-                                   C.c_void_p(d_ceps.data_ptr()), f_off.ctypes.data_as(u64p), C.byref(nb)), ctx.handle)
+    d_ceps = ctx.alloc(4 * n * 2048 * 13)
+    apd.check(L.apd_cepstrum_batch(ctx.handle, d_audio.at(), s_off.ctypes.data_as(u64p), n, 256, 128, 18, 1,
+                                   d_ceps.at(), f_off.ctypes.data_as(u64p), C.byref(nb)), ctx.handle)
     assert nb.value == 13 and f_off.tolist() == [2048 * k for k in range(n + 1)]
     batch = C.c_void_p()
-    apd.check(L.apd_batch_create(ctx.handle, C.c_void_p(d_ceps.data_ptr()), f_off.ctypes.data_as(u64p), n, 13, 1, C.byref(batch)), ctx.handle)
+    apd.check(L.apd_batch_create(ctx.handle, d_ceps.at(), f_off.ctypes.data_as(u64p), n, 13, 1, C.byref(batch)), ctx.handle)
     cfg = apd.AlignConfig(0.0625, 1.0, 1.0, 1.0)
-    d_out = torch.full((n * n,), float("nan"), dtype=torch.float32, device="cuda")
-    apd.check(L.apd_align_all_device_async(ctx.handle, batch, C.byref(cfg), C.c_void_p(d_out.data_ptr())), ctx.handle)
+    d_out = ctx.alloc(4 * n * n)
+    d_out.fill(0xFF)                                                     # NaN
+    apd.check(L.apd_align_all_device_async(ctx.handle, batch, C.byref(cfg), d_out.at()), ctx.handle)
     ctx.synchronize()
-    got = d_out.cpu().numpy().reshape(n, n)
-    ceps = d_ceps.cpu().numpy().reshape(n, 2048, 13)
+    got = d_out.to_numpy(np.float32).reshape(n, n)
+    ceps = d_ceps.to_numpy(np.float32).reshape(n, 2048, 13)
     L.apd_batch_destroy(batch)
+    # the UPGMA leg on the RESIDENT matrix (cepstrum -> DTW -> UPGMA never leaves HBM), against the O(n^3) oracle restatement of
+    # clustering.rs:81-209 on the same matrix: ops, kinds, roots, threshold and linkage BITS
+    ops = (apd.ClusterOp * n)()
+    roots = np.zeros(n, dtype=np.uint32)
+    n_ops, n_roots, thr = C.c_uint32(0), C.c_uint32(0), C.c_float(0)
+    for perc in (0.05, 0.5):
+        apd.check(L.apd_clustering(ctx.handle, d_out.at(), 1, n, perc, ops, C.byref(n_ops), roots.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                   C.byref(n_roots), C.byref(thr)), ctx.handle)
+        want_ops, want_roots, want_thr = oracle.clustering(got, n, perc, fast=True)
+        assert n_ops.value == len(want_ops) and n_ops.value >= 1
+        names = ["Sequence2Sequence", "Sequence2Cluster", "Cluster2Sequence", "Cluster2Cluster"]
+        assert [(ops[k].merge_i, ops[k].merge_j, ops[k].into, names[ops[k].operation]) for k in range(n_ops.value)] == \
+               [(o["merge_i"], o["merge_j"], o["into"], o["operation"]) for o in want_ops]
+        assert np.array_equal(np.array([ops[k].distance for k in range(n_ops.value)], np.float32).view(np.uint32),
+                              np.array([o["distance"] for o in want_ops], np.float32).view(np.uint32))
+        assert roots[:n_roots.value].tolist() == sorted(want_roots)
+        assert np.float32(thr.value).view(np.uint32) == np.float32(want_thr).view(np.uint32)
+    assert (ops[0].merge_i, ops[0].merge_j) in ((40, 200), (200, 40))    # the exact repeat merges first (distance 0)
     # properties
     assert np.all(np.diag(got) == 0.0)
     off = ~np.eye(n, dtype=bool)
@@ -100,7 +118,6 @@ def test_cfg5_shape_audio_to_matrix_on_device(ctx, oracle, apd):
 
 
 def test_cfg4_full_size_through_the_encoder(ctx, oracle, apd):
-    import torch
     L = apd.lib()
     n = 4096
     frames, offsets = synth.make_sequences(n, 1024, 13, seed=0xA9D4)
@@ -108,19 +125,19 @@ def test_cfg4_full_size_through_the_encoder(ctx, oracle, apd):
     w = ((rng.random((13, 8)) - 0.5) / 8).astype(np.float32)             # Mat::seeded scale (numerics.rs:178-186)
     b = ((rng.random(8) - 0.5) / 8).astype(np.float32)
     total = int(offsets[-1])
-    d_src = torch.from_numpy(frames).cuda()
-    d_lat = torch.empty(total * 8, dtype=torch.float32, device="cuda")
-    apd.check(L.apd_encode(ctx.handle, C.c_void_p(d_src.data_ptr()), total, 13, w.ctypes.data_as(f32p), b.ctypes.data_as(f32p), 8, 1,
-                           C.c_void_p(d_lat.data_ptr())), ctx.handle)
+    d_src = ctx.upload(frames)
+    d_lat = ctx.alloc(4 * total * 8)
+    apd.check(L.apd_encode(ctx.handle, d_src.at(), total, 13, w.ctypes.data_as(f32p), b.ctypes.data_as(f32p), 8, 1, d_lat.at()), ctx.handle)
     off_c = np.ascontiguousarray(offsets, dtype=np.uint64)
     batch = C.c_void_p()
-    apd.check(L.apd_batch_create(ctx.handle, C.c_void_p(d_lat.data_ptr()), off_c.ctypes.data_as(u64p), n, 8, 1, C.byref(batch)), ctx.handle)
+    apd.check(L.apd_batch_create(ctx.handle, d_lat.at(), off_c.ctypes.data_as(u64p), n, 8, 1, C.byref(batch)), ctx.handle)
     cfg = apd.AlignConfig(0.0625, 1.0, 1.0, 1.0)
-    d_out = torch.full((n * n,), float("nan"), dtype=torch.float32, device="cuda")
-    apd.check(L.apd_align_all_device_async(ctx.handle, batch, C.byref(cfg), C.c_void_p(d_out.data_ptr())), ctx.handle)
+    d_out = ctx.alloc(4 * n * n)
+    d_out.fill(0xFF)                                                     # NaN
+    apd.check(L.apd_align_all_device_async(ctx.handle, batch, C.byref(cfg), d_out.at()), ctx.handle)
     ctx.synchronize()
-    got = d_out.cpu().numpy().reshape(n, n)
-    lat = d_lat.cpu().numpy().reshape(total, 8)
+    got = d_out.to_numpy(np.float32).reshape(n, n)
+    lat = d_lat.to_numpy(np.float32).reshape(total, 8)
     L.apd_batch_destroy(batch)
     assert np.all(np.diag(got) == 0.0)
     off = ~np.eye(n, dtype=bool)

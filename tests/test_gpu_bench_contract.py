@@ -33,3 +33,25 @@ def test_bench_line_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "cell-updates/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert d["parity_ok"] is True and d["max_rel_err_vs_oracle"] <= 1e-4
+    # no torch in the data path: buffers, streams and fences come from the library; the runtime is the one it links
+    assert d["config"]["torch_imported"] is False and "/opt/rocm" in d["config"]["runtime"]
+    assert d["config"]["collective_fallback"] is False and d["config"]["ranks_seen"] == 1
+    # the full-matrix census of the default distance form against the bit-exact strict mode
+    pc = d["parity_census"]
+    assert pc["entries"] == 64 * 64 and pc["over_1e-4"] == 0 and pc["max_rel"] <= 1e-4
+    assert pc["nonfinite_pattern_equal"] and pc["zero_pattern_equal"] and pc["strict_max_rel_err_vs_oracle"] == 0.0
+
+
+def test_bench_secondary_workloads_and_in_process_multi_device():
+    """`--gpus 1 --launcher inprocess`-style multi handle at one device is covered by tests/test_gpu_multi.py; here: the
+    `secondary` object (cfg1 measured next to another workload in the same run)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg2", "--steps", "2", "--warmup", "1",
+                          "--cpu-seconds", "0", "--secondary", "on"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["workload"].startswith("cfg2") and d["parity_census"]["over_1e-4"] == 0
+    for name in ("cfg2", "cfg1"):
+        s = d["secondary"][name]
+        assert s["workload"].startswith(name) and s["kernel_ms"] > 0 and 0 < s["roofline_frac"] < 1 and s["parity_ok"] is True
+    # the same shape measured twice in one run agrees with itself
+    assert abs(d["secondary"]["cfg2"]["kernel_ms"] / d["roofline"]["kernel_ms"] - 1.0) < 0.15

@@ -162,6 +162,36 @@ def test_large_matrices_match_fast_oracle(ctx, oracle, n, kind, perc):
         assert len(ops) > n // 2                                     # the run really went deep into the dendrogram
 
 
+@pytest.mark.parametrize("kind,perc", [("points", 0.05), ("ties", 0.3)])
+def test_cfg5_size_matrix_matches_fast_oracle(ctx, oracle, kind, perc):
+    """N = 16384 (BASELINE cfg 5's matrix: 1 GiB, 2.6 GB of UPGMA state on the device): the same comparison as above at the size
+    the survey's row f1 names.  The O(n^3) oracle stays at tens of seconds because these dendrograms are balanced (many small
+    clusters: a merge re-sums |Ci| x n terms)."""
+    import os
+    from audio_pattern_discovery_amd.clustering import AgglomerativeClustering
+    n = 16384
+    try:
+        avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (ValueError, OSError):
+        avail = 0
+    if avail < 6 * (1 << 30):
+        pytest.skip("needs ~6 GB of free host memory for the matrix and the oracle's copies")
+    d = synth.make_distance_matrix(n, kind, seed=n + len(kind))
+    want_ops, want_roots, want_thr = oracle.clustering(d, n, perc, fast=True)
+    ops, roots, thr = AgglomerativeClustering.clustering(d, n, perc, ctx, return_threshold=True)
+    assert thr == want_thr
+    assert len(ops) == len(want_ops) and len(ops) > 1000
+    got = np.array([(o.merge_i, o.merge_j, o.into, int(o.operation)) for o in ops], dtype=np.int64).reshape(-1, 4)
+    names = {"Sequence2Sequence": 0, "Sequence2Cluster": 1, "Cluster2Sequence": 2, "Cluster2Cluster": 3}
+    want = np.array([(o["merge_i"], o["merge_j"], o["into"], names[o["operation"]]) for o in want_ops], dtype=np.int64).reshape(-1, 4)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, "first differing merge %d: got %s want %s" % (bad[0], got[bad[0]], want[bad[0]])
+    gd = np.array([o.distance for o in ops], dtype=np.float32)
+    wd = np.array([o["distance"] for o in want_ops], dtype=np.float32)
+    assert np.array_equal(gd.view(np.uint32), wd.view(np.uint32)), "linkage bits differ"
+    assert sorted(roots) == want_roots
+
+
 @pytest.mark.parametrize("kind", ["subnormal", "overflow", "decades", "zeros", "negative", "nan_inf", "integers"])
 def test_exact_sums_survive_extreme_value_ranges(ctx, oracle, kind):
     """The parallel evaluation of linkage()'s sequential f32 sum (integer maps per binade, speculative segments) at its corners:

@@ -101,7 +101,6 @@ def test_encoder_shapes_and_alignment(ctx, oracle, apd):
     """The staged encoder (64 frames per wavefront through LDS): frame counts around the chunk size, even and odd dimensions
     (row padding), an output that does not start on a 16-byte boundary, and the un-staged fallback for wide frames."""
     import ctypes as C
-    import torch
     from audio_pattern_discovery_amd.neural import AutoEncoder
     rng = np.random.default_rng(11)
     for d_in, latent, t in [(13, 8, 63), (13, 8, 64), (13, 8, 65), (26, 10, 1000), (12, 7, 129), (16, 16, 257), (3, 2, 1), (200, 40, 300)]:
@@ -114,14 +113,15 @@ def test_encoder_shapes_and_alignment(ctx, oracle, apd):
     x = (rng.standard_normal((t, d_in)) * 2).astype(np.float32)
     w = ((rng.random((d_in, latent)) - 0.5) / latent).astype(np.float32)
     b = ((rng.random(latent) - 0.5) / latent).astype(np.float32)
-    d_x = torch.zeros(t * d_in + 1, dtype=torch.float32, device="cuda")
-    d_x[1:] = torch.from_numpy(x.ravel()).cuda()
-    d_z = torch.zeros(t * latent + 3, dtype=torch.float32, device="cuda")
+    d_x = ctx.alloc(4 * (t * d_in + 1))
+    d_x.copy_from(x.ravel(), byte_offset=4)
+    d_z = ctx.alloc(4 * (t * latent + 3))
+    d_z.fill(0)
     f32p = C.POINTER(C.c_float)
-    apd.check(apd.lib().apd_encode(ctx.handle, C.c_void_p(d_x.data_ptr() + 4), t, d_in, w.ctypes.data_as(f32p), b.ctypes.data_as(f32p), latent, 1,
-                                   C.c_void_p(d_z.data_ptr() + 12)), ctx.handle)
+    apd.check(apd.lib().apd_encode(ctx.handle, d_x.at(4), t, d_in, w.ctypes.data_as(f32p), b.ctypes.data_as(f32p), latent, 1,
+                                   d_z.at(12)), ctx.handle)
     ctx.synchronize()
-    np.testing.assert_allclose(d_z.cpu().numpy()[3:].reshape(t, latent), oracle.encode(x, w, b), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(d_z.to_numpy(np.float32)[3:].reshape(t, latent), oracle.encode(x, w, b), rtol=1e-5, atol=1e-5)
 
 
 def test_audio_to_clusters_on_device(ctx, oracle, apd):
@@ -129,7 +129,6 @@ def test_audio_to_clusters_on_device(ctx, oracle, apd):
     apd_encode -> apd_batch_create(frames_on_device) -> align_all, against the oracle pipeline (main.rs:150-161 then
     187-195).  Cepstrum parity is unpinned (see module docstring): DTW costs agree to 1e-3."""
     import ctypes as C
-    import torch
     L = apd.lib()
     rng = np.random.default_rng(5)
     lens = rng.integers(256 + 128 * 20, 256 + 128 * 40, size=12)
@@ -140,23 +139,22 @@ def test_audio_to_clusters_on_device(ctx, oracle, apd):
     w = ((rng.random((13, 8)) - 0.5) / 8).astype(np.float32)
     b = ((rng.random(8) - 0.5) / 8).astype(np.float32)
     n = len(audio)
-    d_samples = torch.from_numpy(samples).cuda()
+    d_samples = ctx.upload(samples)
     f_off = np.zeros(n + 1, dtype=np.uint64)
     nb = C.c_uint32(0)
     u64p = C.POINTER(C.c_uint64)
-    apd.check(L.apd_cepstrum_batch(ctx.handle, C.c_void_p(d_samples.data_ptr()), s_off.ctypes.data_as(u64p), n, 256, 128, 18, 1,
+    apd.check(L.apd_cepstrum_batch(ctx.handle, d_samples.at(), s_off.ctypes.data_as(u64p), n, 256, 128, 18, 1,
                                    None, f_off.ctypes.data_as(u64p), C.byref(nb)), ctx.handle)
     assert nb.value == 13
     total = int(f_off[-1])
-    d_ceps = torch.empty(total * 13, dtype=torch.float32, device="cuda")
-    apd.check(L.apd_cepstrum_batch(ctx.handle, C.c_void_p(d_samples.data_ptr()), s_off.ctypes.data_as(u64p), n, 256, 128, 18, 1,
-                                   C.c_void_p(d_ceps.data_ptr()), f_off.ctypes.data_as(u64p), C.byref(nb)), ctx.handle)
-    d_lat = torch.empty(total * 8, dtype=torch.float32, device="cuda")
+    d_ceps = ctx.alloc(4 * total * 13)
+    apd.check(L.apd_cepstrum_batch(ctx.handle, d_samples.at(), s_off.ctypes.data_as(u64p), n, 256, 128, 18, 1,
+                                   d_ceps.at(), f_off.ctypes.data_as(u64p), C.byref(nb)), ctx.handle)
+    d_lat = ctx.alloc(4 * total * 8)
     f32p = C.POINTER(C.c_float)
-    apd.check(L.apd_encode(ctx.handle, C.c_void_p(d_ceps.data_ptr()), total, 13, w.ctypes.data_as(f32p), b.ctypes.data_as(f32p), 8, 1,
-                           C.c_void_p(d_lat.data_ptr())), ctx.handle)
+    apd.check(L.apd_encode(ctx.handle, d_ceps.at(), total, 13, w.ctypes.data_as(f32p), b.ctypes.data_as(f32p), 8, 1, d_lat.at()), ctx.handle)
     batch = C.c_void_p()
-    apd.check(L.apd_batch_create(ctx.handle, C.c_void_p(d_lat.data_ptr()), f_off.ctypes.data_as(u64p), n, 8, 1, C.byref(batch)), ctx.handle)
+    apd.check(L.apd_batch_create(ctx.handle, d_lat.at(), f_off.ctypes.data_as(u64p), n, 8, 1, C.byref(batch)), ctx.handle)
     cfg = apd.AlignConfig(0.0625, 1, 1, 1)
     got = np.empty((n, n), dtype=np.float32)
     apd.check(L.apd_align_all(ctx.handle, batch, C.byref(cfg), got.ctypes.data_as(f32p)), ctx.handle)
@@ -165,7 +163,7 @@ def test_audio_to_clusters_on_device(ctx, oracle, apd):
     feats = [oracle.encode(oracle.cepstrum(a, 256, 128, 18), w, b) for a in audio]
     assert [len(f) for f in feats] == np.diff(f_off).astype(int).tolist()
     want = oracle.align_all(np.concatenate(feats), f_off, 0.0625, workers=4)
-    np.testing.assert_allclose(d_ceps.cpu().numpy().reshape(total, 13), np.concatenate([oracle.cepstrum(a, 256, 128, 18) for a in audio]),
+    np.testing.assert_allclose(d_ceps.to_numpy(np.float32).reshape(total, 13), np.concatenate([oracle.cepstrum(a, 256, 128, 18) for a in audio]),
                                rtol=0, atol=3e-4)
     assert got[2, 7] == 0.0 and got[7, 2] == 0.0
     np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-5)

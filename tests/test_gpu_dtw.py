@@ -171,7 +171,6 @@ def test_kat_through_the_gpu(ctx):
 def test_sharded_tiles_equal_single_launch(ctx, apd, oracle):
     """world=3 slabs computed one after the other on one GPU, concatenated as an all-gather would,
     then unpacked, must equal the single-launch matrix (the multi-GPU data path minus RCCL)."""
-    import torch
     from audio_pattern_discovery_amd.alignments import Batch
     from audio_pattern_discovery_amd.discovery import Discovery
     frames, offsets = synth.make_sequences(70, 60, 13, seed=4)
@@ -180,15 +179,14 @@ def test_sharded_tiles_equal_single_launch(ctx, apd, oracle):
     batch = Batch(ctx, frames, offsets, 13)
     n, world = 70, 3
     slab = int(L.apd_slab_floats(n, world))
-    gathered = torch.zeros(world * slab, dtype=torch.float32, device="cuda")
+    gathered = ctx.alloc(4 * world * slab)
+    gathered.fill(0)
     for r in range(world):
-        apd.check(L.apd_align_tiles_async(ctx.handle, batch.handle, C.byref(cfg), r, world,
-                                          C.c_void_p(gathered.data_ptr() + 4 * r * slab)), ctx.handle)
-    out = torch.empty(n * n, dtype=torch.float32, device="cuda")
-    apd.check(L.apd_unpack_tiles_async(ctx.handle, batch.handle, world, C.c_void_p(gathered.data_ptr()), C.c_void_p(out.data_ptr())),
-              ctx.handle)
+        apd.check(L.apd_align_tiles_async(ctx.handle, batch.handle, C.byref(cfg), r, world, gathered.at(4 * r * slab)), ctx.handle)
+    out = ctx.alloc(4 * n * n)
+    apd.check(L.apd_unpack_tiles_async(ctx.handle, batch.handle, world, gathered.at(), out.at()), ctx.handle)
     ctx.synchronize()
-    assert_parity(out.cpu().numpy().reshape(n, n), oracle.align_all(frames, offsets, 0.0625, workers=8))
+    assert_parity(out.to_numpy(np.float32).reshape(n, n), oracle.align_all(frames, offsets, 0.0625, workers=8))
 
 
 def test_full_size_properties_cfg2(ctx, oracle):
@@ -218,7 +216,6 @@ def test_full_size_properties_cfg3(ctx, oracle):
     """BASELINE cfg 3 shape (4096 x len~1024, band 64: 16.8 M ordered pairs) through the device entry points:
     size-independent properties + sampled entries against the oracle + a checksum that must not depend on how
     the pair tiles are sharded (world 1 vs world 4 slabs)."""
-    import torch
     from audio_pattern_discovery_amd.alignments import Batch
     from audio_pattern_discovery_amd.discovery import Discovery
     from audio_pattern_discovery_amd import _lib
@@ -229,10 +226,10 @@ def test_full_size_properties_cfg3(ctx, oracle):
     cfg = Discovery(warping_band_percentage=0.0625).align_config()
     L = _lib.lib()
     batch = Batch(ctx, frames, offsets, 13)
-    out = torch.empty(n * n, dtype=torch.float32, device="cuda")
-    _lib.check(L.apd_align_all_device_async(ctx.handle, batch.handle, C.byref(cfg), C.c_void_p(out.data_ptr())), ctx.handle)
+    out = ctx.alloc(4 * n * n)
+    _lib.check(L.apd_align_all_device_async(ctx.handle, batch.handle, C.byref(cfg), out.at()), ctx.handle)
     ctx.synchronize()
-    got = out.cpu().numpy().reshape(n, n)
+    got = out.to_numpy(np.float32).reshape(n, n)
     assert np.all(np.diag(got) == 0.0)
     off = ~np.eye(n, dtype=bool)
     assert np.all(np.isfinite(got[off])) and np.all(got[off] >= 0)
@@ -245,14 +242,14 @@ def test_full_size_properties_cfg3(ctx, oracle):
     # sharding invariance: 4 slabs computed separately, unpacked, give the identical matrix (bitwise)
     world = 4
     slab = int(L.apd_slab_floats(n, world))
-    gathered = torch.zeros(world * slab, dtype=torch.float32, device="cuda")
+    gathered = ctx.alloc(4 * world * slab)
+    gathered.fill(0)
     for r in range(world):
-        _lib.check(L.apd_align_tiles_async(ctx.handle, batch.handle, C.byref(cfg), r, world,
-                                           C.c_void_p(gathered.data_ptr() + 4 * r * slab)), ctx.handle)
-    out2 = torch.empty(n * n, dtype=torch.float32, device="cuda")
-    _lib.check(L.apd_unpack_tiles_async(ctx.handle, batch.handle, world, C.c_void_p(gathered.data_ptr()), C.c_void_p(out2.data_ptr())), ctx.handle)
+        _lib.check(L.apd_align_tiles_async(ctx.handle, batch.handle, C.byref(cfg), r, world, gathered.at(4 * r * slab)), ctx.handle)
+    out2 = ctx.alloc(4 * n * n)
+    _lib.check(L.apd_unpack_tiles_async(ctx.handle, batch.handle, world, gathered.at(), out2.at()), ctx.handle)
     ctx.synchronize()
-    assert torch.equal(out, out2)
+    assert np.array_equal(got.view(np.uint32), out2.to_numpy(np.uint32).reshape(n, n))
 
 
 @pytest.mark.parametrize("scale", [0.0, 1e-4, 1e-3, 1e-2, 0.1, 0.5, 2.0])
@@ -370,7 +367,6 @@ def test_launches_are_cut_below_the_work_item_limit(ctx, oracle):
     """11700 short sequences on a 64-lanes-per-pair kernel: 268 278 tiles x 16 384 work-items exceed 2^32, beyond which the
     runtime cuts a grid short without an error; launch_align issues runs of tiles instead.  (cfg 5 -- 16384 recordings,
     band 128 -- is the BASELINE configuration that crosses this limit.)"""
-    import torch
     from audio_pattern_discovery_amd import _lib
     n, dim = 11700, 13
     rng = np.random.default_rng(3)
@@ -378,25 +374,26 @@ def test_launches_are_cut_below_the_work_item_limit(ctx, oracle):
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     frames = rng.standard_normal((int(offsets[-1]), dim)).astype(np.float32)
     L = _lib.lib()
-    d_frames = torch.from_numpy(frames).cuda()
+    d_frames = ctx.upload(frames)
     batch = C.c_void_p()
-    _lib.check(L.apd_batch_create(ctx.handle, C.c_void_p(d_frames.data_ptr()), offsets.ctypes.data_as(C.POINTER(C.c_uint64)), n, dim, 1,
+    _lib.check(L.apd_batch_create(ctx.handle, d_frames.at(), offsets.ctypes.data_as(C.POINTER(C.c_uint64)), n, dim, 1,
                                   C.byref(batch)), ctx.handle)
     cfg = _lib.AlignConfig(1.0, 1.0, 1.0, 1.0)
-    d_out = torch.empty(n * n, dtype=torch.float32, device="cuda")
-    _lib.check(L.apd_align_all_device_async(ctx.handle, batch, C.byref(cfg), C.c_void_p(d_out.data_ptr())), ctx.handle)
-    torch.cuda.synchronize()
+    d_out = ctx.alloc(4 * n * n)
+    _lib.check(L.apd_align_all_device_async(ctx.handle, batch, C.byref(cfg), d_out.at()), ctx.handle)
+    ctx.synchronize()
+    full = d_out.to_numpy(np.float32).reshape(n, n)
     order = np.argsort(-lens, kind="stable")                     # tiles follow the length order: sample its head, middle and tail
     pos_i = np.concatenate([rng.integers(0, n, 200), [0, 1, n - 1, n - 2, n // 2]])
     pos_j = np.concatenate([rng.integers(0, n, 200), [n - 1, n - 3, n - 5, 0, n - 1]])
     keep = pos_i != pos_j
     pi, pj = order[pos_i[keep]].astype(np.uint32), order[pos_j[keep]].astype(np.uint32)
     want, _ = oracle.align_sample(frames, offsets, pi, pj, 1.0, workers=8)
-    got = d_out.view(n, n)[torch.from_numpy(pi.astype(np.int64)), torch.from_numpy(pj.astype(np.int64))].cpu().numpy()
+    got = full[pi, pj]
     L.apd_batch_destroy(batch)
     assert_parity(got, want)
-    assert float(d_out.view(n, n).diagonal().abs().max()) == 0.0
-    assert int((d_out == 0).sum()) == n                          # nothing left unwritten: only the diagonal is zero
+    assert float(np.abs(np.diag(full)).max()) == 0.0
+    assert int((full == 0).sum()) == n                           # nothing left unwritten: only the diagonal is zero
 
 
 @pytest.mark.parametrize("dim", [13, 26])
@@ -565,13 +562,13 @@ def test_a_shortened_launch_is_reported_not_zero_filled(ctx, oracle, apd):
     assert_parity(got[ok], want[ok])                                      # what was written is right
     assert np.all(np.diag(got) == 0.0)
     # the asynchronous entry points report through apd_synchronize, once
-    import torch
     from audio_pattern_discovery_amd.alignments import Batch
     b = Batch(ctx, frames, offsets, 13)
     cfg = Discovery(warping_band_percentage=0.0625).align_config()
-    out = torch.zeros(n * n, dtype=torch.float32, device="cuda")
+    out = ctx.alloc(4 * n * n)
+    out.fill(0)
     ctx.set_fault_injection(1)
-    apd.check(apd.lib().apd_align_all_device_async(ctx.handle, b.handle, C.byref(cfg), C.c_void_p(out.data_ptr())), ctx.handle)
+    apd.check(apd.lib().apd_align_all_device_async(ctx.handle, b.handle, C.byref(cfg), out.at()), ctx.handle)
     ctx.set_fault_injection(0)
     with pytest.raises(apd.ApdError) as e2:
         ctx.synchronize()
@@ -582,7 +579,6 @@ def test_a_shortened_launch_is_reported_not_zero_filled(ctx, oracle, apd):
 
 
 def test_batch_refill_keeps_plans_and_takes_new_values(ctx, oracle, apd):
-    import torch
     from audio_pattern_discovery_amd.alignments import Batch
     from audio_pattern_discovery_amd.discovery import Discovery
     n = 40
@@ -591,21 +587,21 @@ def test_batch_refill_keeps_plans_and_takes_new_values(ctx, oracle, apd):
     cfg = Discovery(warping_band_percentage=0.0625).align_config()
     L = apd.lib()
     b = Batch(ctx, f1, offsets, 13)
-    out = torch.empty(n * n, dtype=torch.float32, device="cuda")
-    apd.check(L.apd_align_all_device_async(ctx.handle, b.handle, C.byref(cfg), C.c_void_p(out.data_ptr())), ctx.handle)
+    out = ctx.alloc(4 * n * n)
+    apd.check(L.apd_align_all_device_async(ctx.handle, b.handle, C.byref(cfg), out.at()), ctx.handle)
     ctx.synchronize()
-    assert_parity(out.cpu().numpy().reshape(n, n), oracle.align_all(f1, offsets, 0.0625, workers=8))
-    d_f2 = torch.from_numpy(f2).cuda()
-    apd.check(L.apd_batch_refill(ctx.handle, b.handle, C.c_void_p(d_f2.data_ptr()), 1), ctx.handle)
-    apd.check(L.apd_align_all_device_async(ctx.handle, b.handle, C.byref(cfg), C.c_void_p(out.data_ptr())), ctx.handle)
+    assert_parity(out.to_numpy(np.float32).reshape(n, n), oracle.align_all(f1, offsets, 0.0625, workers=8))
+    d_f2 = ctx.upload(f2)
+    apd.check(L.apd_batch_refill(ctx.handle, b.handle, d_f2.at(), 1), ctx.handle)
+    apd.check(L.apd_align_all_device_async(ctx.handle, b.handle, C.byref(cfg), out.at()), ctx.handle)
     ctx.synchronize()
-    assert_parity(out.cpu().numpy().reshape(n, n), oracle.align_all(f2, offsets, 0.0625, workers=8))
+    assert_parity(out.to_numpy(np.float32).reshape(n, n), oracle.align_all(f2, offsets, 0.0625, workers=8))
     f3 = f1.copy()
     f3[11, 3] = np.nan                                                    # a refill re-evaluates the non-finite flag
     apd.check(L.apd_batch_refill(ctx.handle, b.handle, f3.ctypes.data_as(C.POINTER(C.c_float)), 0), ctx.handle)
-    apd.check(L.apd_align_all_device_async(ctx.handle, b.handle, C.byref(cfg), C.c_void_p(out.data_ptr())), ctx.handle)
+    apd.check(L.apd_align_all_device_async(ctx.handle, b.handle, C.byref(cfg), out.at()), ctx.handle)
     ctx.synchronize()
-    _assert_same_bits_or_nan(out.cpu().numpy().reshape(n, n), oracle.align_all(f3, offsets, 0.0625, workers=8))
+    _assert_same_bits_or_nan(out.to_numpy(np.float32).reshape(n, n), oracle.align_all(f3, offsets, 0.0625, workers=8))
 
 
 # ---- the multi-GPU entry points on the one GPU a test box has ---------------------------------------------------------
@@ -629,7 +625,6 @@ def test_align_all_multi_one_device_equals_align_all(ctx, oracle, apd):
 def test_sharded_async_through_a_library_owned_communicator(ctx, oracle, apd):
     """One process per GPU form with world = 1: unique id -> apd_comm_create -> apd_align_all_sharded_async (tiles, ncclAllGather
     on the context's stream, unpack) equals apd_align_all_device_async bit for bit; apd_all_gather_async moves data."""
-    import torch
     from audio_pattern_discovery_amd import sharding
     from audio_pattern_discovery_amd.alignments import Batch
     from audio_pattern_discovery_amd.discovery import Discovery
@@ -639,18 +634,18 @@ def test_sharded_async_through_a_library_owned_communicator(ctx, oracle, apd):
     comm = sharding.Comm(ctx, sharding.Comm.unique_id(), 0, 1)
     assert comm.count() == 1 and comm.rank() == 0
     b = Batch(ctx, frames, offsets, 13)
-    a = torch.empty(n * n, dtype=torch.float32, device="cuda")
-    c = torch.empty(n * n, dtype=torch.float32, device="cuda")
-    comm.align_all_sharded_async(b.handle, cfg, a.data_ptr())
-    apd.check(apd.lib().apd_align_all_device_async(ctx.handle, b.handle, C.byref(cfg), C.c_void_p(c.data_ptr())), ctx.handle)
+    a, c = ctx.alloc(4 * n * n), ctx.alloc(4 * n * n)
+    comm.align_all_sharded_async(b.handle, cfg, a.ptr)
+    apd.check(apd.lib().apd_align_all_device_async(ctx.handle, b.handle, C.byref(cfg), c.at()), ctx.handle)
     ctx.synchronize()
-    assert torch.equal(a, c)
-    assert_parity(a.cpu().numpy().reshape(n, n), oracle.align_all(frames, offsets, 0.0625, workers=8))
-    src = torch.arange(1000, dtype=torch.float32, device="cuda")
-    dst = torch.zeros(1000, dtype=torch.float32, device="cuda")
-    apd.check(apd.lib().apd_all_gather_async(ctx.handle, comm.handle, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), 1000), ctx.handle)
+    assert np.array_equal(a.to_numpy(np.uint32), c.to_numpy(np.uint32))
+    assert_parity(a.to_numpy(np.float32).reshape(n, n), oracle.align_all(frames, offsets, 0.0625, workers=8))
+    src = ctx.upload(np.arange(1000, dtype=np.float32))
+    dst = ctx.alloc(4000)
+    dst.fill(0)
+    apd.check(apd.lib().apd_all_gather_async(ctx.handle, comm.handle, src.at(), dst.at(), 1000), ctx.handle)
     ctx.synchronize()
-    assert torch.equal(src, dst)
+    assert np.array_equal(dst.to_numpy(np.float32), np.arange(1000, dtype=np.float32))
     comm.close()
     # destruction order is the caller's: a context may go before its communicator (and its batches)
     ctx2 = apd.Context(0)

@@ -1,0 +1,136 @@
+"""The persistent multi-device handle (include/apd.h: apd_multi_*) on the one GPU a test box has: contexts, RCCL
+communicators (ncclCommInitAll), worker threads, gather buffers and resident batches are made once; the second align_all
+pays kernels + one all-gather + unpack only.  Replaces AlignmentWorkers { data, result } + align_all's thread fan-out
+(reference src/alignments.rs:11-67) for N GPUs; the N > 1 branch proper runs on the driver's 8-GPU node (bench.py --gpus N)."""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import pytest
+
+from audio_pattern_discovery_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_parity(got, want):
+    assert np.array_equal(np.isfinite(got), np.isfinite(want))
+    f = np.isfinite(want) & (want != 0)
+    assert np.all(got[np.isfinite(want) & (want == 0)] == 0)
+    assert np.max(np.abs(got[f] - want[f]) / np.abs(want[f])) <= 1e-4          # the north star's tolerance
+
+
+def test_create_once_align_many(apd, oracle):
+    """First call = handle + batch + alignment; the second alignment on the same handle must give the identical bits and be
+    at least 3x faster (no communicator, context, batch or plan is rebuilt)."""
+    from audio_pattern_discovery_amd import sharding
+    from audio_pattern_discovery_amd.alignments import Batch
+    n = 96
+    frames, offsets = synth.make_sequences(n, 80, 13, seed=21)
+    cfg = apd.AlignConfig(0.0625, 1.0, 1.0, 1.0)
+    t0 = time.perf_counter()
+    m = sharding.Multi([0])
+    mb = m.batch(offsets, 13, frames=frames)
+    first = m.align_all(mb, cfg)
+    t_first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    second = m.align_all(mb, cfg)
+    t_second = time.perf_counter() - t0
+    assert np.array_equal(first.view(np.uint32), second.view(np.uint32))
+    assert t_second * 3 <= t_first, "second call %.4f s vs first %.4f s" % (t_second, t_first)
+    assert m.ranks_seen() == 1 and m.collective().startswith("rccl")
+    assert_parity(first, oracle.align_all(frames, offsets, 0.0625, workers=8))
+    # the same bits as the single-device entry point
+    ctx = apd.Context(0)
+    single = np.empty((n, n), np.float32)
+    b = Batch(ctx, frames, offsets, 13)
+    apd.check(apd.lib().apd_align_all(ctx.handle, b.handle, C.byref(cfg), single.ctypes.data_as(C.POINTER(C.c_float))), ctx.handle)
+    assert np.array_equal(first.view(np.uint32), single.view(np.uint32))
+    mb.close()
+    m.close()
+
+
+def test_device_resident_frames_refill_and_async(apd, oracle):
+    """Frames resident on the handle's device (apd_multi_context + apd_device_alloc), refilled with new values of the same
+    lengths, aligned asynchronously into a caller's buffer and into the handle's own result."""
+    from audio_pattern_discovery_amd import sharding
+    n = 50
+    f1, offsets = synth.make_sequences(n, 64, 13, seed=5)
+    f2 = (f1[::-1] * np.float32(0.5)).copy()
+    cfg = apd.AlignConfig(0.0625, 1.0, 1.0, 1.0)
+    m = sharding.Multi([0])
+    c0 = m.contexts[0]
+    d_f = c0.upload(f1)
+    mb = m.batch(offsets, 13, d_frames=[d_f.ptr])
+    d_out = c0.alloc(4 * n * n)
+    m.align_all_async(mb, cfg, d_out.ptr)
+    m.synchronize()
+    assert_parity(d_out.to_numpy(np.float32).reshape(n, n), oracle.align_all(f1, offsets, 0.0625, workers=8))
+    d_f.copy_from(f2)
+    mb.refill(d_frames=[d_f.ptr])
+    m.align_all_async(mb, cfg)                                          # result owned by the handle
+    m.synchronize()
+    assert m.result_ptr() != 0
+    got = np.empty(n * n, np.float32)
+    apd.check(apd.lib().apd_copy_to_host(c0.handle, C.c_void_p(got.ctypes.data), C.c_void_p(m.result_ptr()), got.nbytes), c0.handle)
+    assert_parity(got.reshape(n, n), oracle.align_all(f2, offsets, 0.0625, workers=8))
+    mb.refill(frames=f1)                                                # host frames work for a refill too
+    assert_parity(m.align_all(mb, cfg), oracle.align_all(f1, offsets, 0.0625, workers=8))
+    # per-device settings go through the handle's contexts: strict mode gives the oracle's bits
+    c0.set_distance_mode("strict")
+    strict = m.align_all(mb, cfg)
+    assert np.array_equal(strict.view(np.uint32), oracle.align_all(f1, offsets, 0.0625, workers=8).view(np.uint32))
+    m.close()                                                           # destroys the batch it still holds
+    mb.close()
+
+
+def test_peer_copy_fallback_gives_the_same_bits(apd):
+    """APD_MULTI_COLLECTIVE=peer takes the path the handle falls back to when ncclCommInitAll fails: slabs gathered with
+    hipMemcpyPeerAsync.  Same matrix, and the handle says which collective it runs."""
+    from audio_pattern_discovery_amd import sharding
+    frames, offsets = synth.make_sequences(70, 60, 13, seed=4)
+    cfg = apd.AlignConfig(0.0625, 1.0, 1.0, 1.0)
+    m = sharding.Multi([0])
+    want = m.align_all(m.batch(offsets, 13, frames=frames), cfg)
+    m.close()
+    os.environ["APD_MULTI_COLLECTIVE"] = "peer"
+    try:
+        p = sharding.Multi([0])
+    finally:
+        del os.environ["APD_MULTI_COLLECTIVE"]
+    assert p.collective().startswith("peer-copy fallback: APD_MULTI_COLLECTIVE=peer") and p.ranks_seen() == 1
+    pb = p.batch(offsets, 13, frames=frames)
+    got = p.align_all(pb, cfg)
+    again = p.align_all(pb, cfg)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and np.array_equal(again.view(np.uint32), want.view(np.uint32))
+    p.close()
+
+
+def test_errors_come_back_with_the_device_and_the_text(apd):
+    from audio_pattern_discovery_amd import sharding
+    with pytest.raises(apd.ApdError) as e:
+        sharding.Multi([0, 0])                                           # RCCL refuses two ranks on one device
+    assert e.value.status == apd.APD_ERR_INVALID_ARG
+    with pytest.raises(apd.ApdError) as e:
+        sharding.Multi([0, 4096])
+    assert e.value.status == apd.APD_ERR_NO_DEVICE
+    m = sharding.Multi([0])
+    frames, offsets = synth.make_sequences(8, 30, 13, seed=1)
+    offsets = offsets.copy()
+    offsets[3] = offsets[2]                                              # a zero-length sequence: alignments.rs:120 underflows
+    mb = m.batch(offsets, 13, frames=frames)
+    with pytest.raises(apd.ApdError) as e:
+        m.align_all(mb, apd.AlignConfig(1.0, 1.0, 1.0, 1.0))
+    assert e.value.status == apd.APD_ERR_EMPTY_SEQUENCE and "device 0" in str(e.value)
+    m.close()
+
+
+def test_one_shot_entry_point_is_the_handle(apd, oracle):
+    from audio_pattern_discovery_amd import sharding
+    from audio_pattern_discovery_amd.discovery import Discovery
+    frames, offsets = synth.make_sequences(40, 50, 8, seed=9)
+    cfg = Discovery(warping_band_percentage=0.25).align_config()
+    got, seen = sharding.align_all_multi([0], frames, offsets, 8, cfg)
+    assert seen == 1
+    assert_parity(got, oracle.align_all(frames, offsets, 0.25, workers=8))

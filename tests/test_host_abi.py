@@ -30,8 +30,7 @@ def test_library_exports_every_declared_symbol(apd):
 
 
 def test_no_cpu_fallback(apd):
-    import torch
-    if torch.cuda.is_available():
+    if os.path.exists("/dev/kfd"):
         pytest.skip("GPU present")
     with pytest.raises(apd.ApdError) as e:
         apd.Context(0)
@@ -190,3 +189,18 @@ def test_dendrograms_equal_a_literal_replay_of_the_reference_loop(oracle, apd):
         dendrograms([ClusteringOperation(0, 7, 4, 0.1, Merge.Sequence2Cluster)], {4}, ["A", "B"])
     with pytest.raises(apd.ApdError):
         dendrograms([ClusteringOperation(0, 5, 4, 0.1, Merge.Sequence2Sequence)], {4}, ["A", "B"])     # a leaf without a label
+
+
+def test_bench_gpus_n_starts_in_process():
+    """`python bench.py --gpus 2` (how the driver starts N > 1) must reach the library's multi-device handle instead of asking
+    for a launcher: without a GPU that means APD_ERR_NO_DEVICE from apd_multi_create, not a SystemExit about torchrun."""
+    import subprocess
+    import sys
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("GPU present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "cfg1", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert out.returncode != 0
+    assert "torch.distributed.run" not in out.stderr and "no gfx950 HIP device" in out.stderr, out.stderr[-1500:]
