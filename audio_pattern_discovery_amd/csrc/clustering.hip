@@ -14,6 +14,8 @@
 //   the new cluster's row and column and patches the other rows' caches.  Exact ties resolve to the lowest (id_p, id_q): what the reference does when its HashSet happens
 //   to iterate in ascending order (clustering.rs:180-187); any other order is equally "reference".
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -931,13 +933,23 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
         if (!use_graph) drop_graph();
     }
     (void)hipGetLastError();
+    const bool debug = std::getenv("APD_DEBUG_UPGMA") != nullptr;
+    uint32_t ops_before = 0;
     while (true) {
         if (use_graph) e = hipGraphLaunch(exec, ctx->stream);
         else { enqueue_batch(); e = hipGetLastError(); }
         if (e == hipSuccess) e = hipMemcpyAsync(host_state, st.n_live, sizeof(host_state), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); drop_graph(); return fail(APD_ERR_HIP); }
+        if (debug) std::fprintf(stderr, "[apd] upgma: graph %d, live %u, ops %u, done %u\n", (int)use_graph, host_state[0], host_state[1], host_state[2]);
         if (host_state[2] != 0) break;
+        // every batch performs `batch` merges unless the loop condition failed: a batch without progress would spin forever
+        if (host_state[1] < ops_before + batch) {
+            ctx->last_error = "UPGMA made no progress in a batch of merges (n_ops " + std::to_string(host_state[1]) + " after " + std::to_string(ops_before) + ")";
+            drop_graph();
+            return fail(APD_ERR_HIP);
+        }
+        ops_before = host_state[1];
     }
     drop_graph();
     const uint32_t cnt = host_state[1];

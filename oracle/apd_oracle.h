@@ -87,6 +87,8 @@ int orc_clustering(const float *dist, uint32_t n, float perc, orc_cluster_op *op
  * worst case: linkages are cached per cluster pair and only the merged cluster's row and column are re-summed, in the
  * reference's own order.  Proven equal to the literal loop in tests/test_oracle.py; used to check the device UPGMA at
  * N in the thousands, where the literal O(n^4) loop cannot go.  OpenMP over independent linkages. */
+/* OpenMP threads of orc_clustering_fast (0 = libgomp default, which oversubscribes a CPU-share-limited host). */
+void orc_set_threads(int threads);
 int orc_clustering_fast(const float *dist, uint32_t n, float perc, orc_cluster_op *ops,
                         uint32_t *n_ops, uint32_t *roots, uint32_t *n_roots, float *threshold);
 

@@ -39,6 +39,13 @@ def lib():
     if not os.path.exists(_SO):
         build()
     L = C.CDLL(_SO)
+    try:                                         # the cores this process may use, at most 16 (a GPU box's share per GPU)
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    L.orc_set_threads.restype = None
+    L.orc_set_threads.argtypes = [C.c_int]
+    L.orc_set_threads(max(1, min(cores, 16)))
     f32p, u64p, u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
     L.orc_euclidean.restype = C.c_float
     L.orc_euclidean.argtypes = [f32p, f32p, C.c_uint32]
