@@ -385,7 +385,7 @@ def main():
     rank = int(os.environ.get("RANK", "0")) if ranks_mode else 0
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if ranks_mode else 0
     world = env_world if ranks_mode else max(args.gpus, 1)
-    multi_mode = (not ranks_mode) and world > 1
+    multi_mode = (not ranks_mode) and (world > 1 or os.environ.get("APD_BENCH_FORCE_MULTI") == "1")   # the env: the handle's path at one device (1-GPU boxes)
     args.gpus = world
 
     from audio_pattern_discovery_amd import _lib, sharding

@@ -24,8 +24,11 @@ for path in find("trace/**/*kernel_trace.csv"):
         for row in csv.DictReader(fp):
             if "apd::dtw_" in row.get("Kernel_Name", ""):   # every alignment kernel: dtw_fused_systolic / _wide / _generic, dtw_full_matrix
                 dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
-                print("dur_ns=%d vgpr=%s sgpr=%s lds=%s scratch=%s grid=%s wg=%s %s" % (
-                    dur, row.get("VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"), row.get("Scratch_Size"),
+                # rocprofv3's VGPR_Count column is NOT the compiler's register count on gfx950 (unified 512-entry file, allocated in
+                # blocks of 8): it prints 120 for the kernel -Rpass-analysis=kernel-resource-usage reports at 236 VGPRs / occupancy 2
+                # (tools/check_resources.sh).  Both trace columns are shown as the tool gives them, labelled as such.
+                print("dur_ns=%d trace_vgpr_field=%s trace_accum_vgpr_field=%s (compiler figures: tools/check_resources.sh) sgpr=%s lds=%s scratch=%s grid=%s wg=%s %s" % (
+                    dur, row.get("VGPR_Count"), row.get("Accum_VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"), row.get("Scratch_Size"),
                     row.get("Grid_Size_X"), row.get("Workgroup_Size_X"), row["Kernel_Name"][:60]))
 print("== PMC (summed over dispatches of the alignment kernel; per-dispatch = /n_dispatch) ==")
 for d in find("pmc_*/"):
