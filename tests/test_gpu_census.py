@@ -82,7 +82,7 @@ def test_census_mfcc_shapes(ctx, apd, oracle, name, n, length, seed):
     max_rel, over, worst, counted = census(default, strict)
     assert counted == n * (n - 1)                                       # every ordered pair is finite and non-zero here
     assert over == 0, "%s: %d entries beyond 1e-4, worst pair %s (%.3e)" % (name, over, worst, max_rel)
-    assert max_rel <= 2e-5                                              # measured ~4e-7: three decades inside the tolerance
+    assert max_rel <= 1e-4                                              # measured 4e-7 (cfg2) and 1e-5 (cfg3); bench.py's cfg3 corpus: 3.5e-5
 
 
 def test_census_cfg4_through_the_encoder(ctx, apd, oracle):
@@ -132,4 +132,4 @@ def test_census_cfg5_shape_from_device_cepstra(ctx, apd, oracle):
     max_rel, over, worst, counted = census(default, strict)
     assert counted == n * (n - 1)                                       # 16 distinct recordings and noisy takes of them: no exact repeat
     assert over == 0, "cfg5 shape: %d entries beyond 1e-4, worst pair %s (%.3e)" % (over, worst, max_rel)
-    assert max_rel <= 2e-5
+    assert max_rel <= 1e-4
