@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <new>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/apd.h"
@@ -94,7 +96,8 @@ extern "C" int apd_autoencoder_copy(const void *bytes, const apd_mat_view *mat, 
 }
 
 // discovery.rs:7-36: `key = value  # comment` lines (the flat TOML the reference ships); every one of the 17 fields must
-// be present exactly once (serde fails on a missing or duplicate field); integers for the usize fields.
+// be present exactly once (serde fails on a missing field, TOML on a duplicate key); integers for the usize fields; keys the
+// struct does not have are ignored, as serde does without deny_unknown_fields.
 extern "C" int apd_discovery_parse_toml(const char *text, apd_discovery *out)
 {
     if (!text || !out) return APD_ERR_INVALID_ARG;
@@ -108,6 +111,7 @@ extern "C" int apd_discovery_parse_toml(const char *text, apd_discovery *out)
         {"auto_encoder", 1, &d.auto_encoder}, {"learning_rate", 0, &d.learning_rate}, {"epochs", 1, &d.epochs},
         {"epoch_drop", 0, &d.epoch_drop}, {"drop", 0, &d.drop}};
     bool seen[17] = {false};
+    bool in_table = false;
     const char *p = text;
     while (*p) {
         const char *eol = std::strchr(p, '\n');
@@ -120,11 +124,16 @@ extern "C" int apd_discovery_parse_toml(const char *text, apd_discovery *out)
             const size_t a = s.find_first_not_of(" \t\r"), b = s.find_last_not_of(" \t\r");
             return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
         };
-        if (eq == std::string::npos) { if (!trim(line).empty()) return APD_ERR_INVALID_ARG; continue; }
+        const std::string bare = trim(line);
+        if (!bare.empty() && bare.front() == '[' && bare.back() == ']') { in_table = true; continue; }   // a [table]: what follows is not a field of Discovery
+        if (eq == std::string::npos) { if (!bare.empty()) return APD_ERR_INVALID_ARG; continue; }
         const std::string key = trim(line.substr(0, eq)), val = trim(line.substr(eq + 1));
+        if (key.empty() || val.empty()) return APD_ERR_INVALID_ARG;              // not `key = value`
+        if (in_table) continue;
         int f = -1;
         for (int k = 0; k < 17; ++k) if (key == fields[k].name) f = k;
-        if (f < 0 || seen[f] || val.empty()) return APD_ERR_INVALID_ARG;         // unknown key (serde: deny? the struct ignores none), duplicate
+        if (f < 0) continue;                                                     // unknown key: #[derive(Deserialize)] without deny_unknown_fields ignores it (discovery.rs:7)
+        if (seen[f]) return APD_ERR_INVALID_ARG;                                 // duplicate key: a TOML error
         char *end = nullptr;
         errno = 0;
         if (fields[f].is_int) {
@@ -145,68 +154,77 @@ extern "C" int apd_discovery_parse_toml(const char *text, apd_discovery *out)
 }
 
 // reporting.rs:135-169: results[into] = "[.into [<left> <right> ] ]" with a leaf rendered as its label and an inner node as
-// the string built for it earlier.  The reference keeps every intermediate string in a HashMap; here each root is
-// expanded on demand (same characters).  An op that refers to a cluster no earlier op made is the reference's HashMap
-// index panic: APD_ERR_INVALID_ARG.
+// the string results[operand] holds AT THAT MOMENT of the replay (HashMap::insert overwrites the entry of a repeated id, but a
+// string built earlier has its operands embedded by value).  So every op records which earlier op had made each of its cluster
+// operands when it ran; expansion follows those op indices -- strictly decreasing, hence finite whatever the ids are (an op
+// whose `into` equals one of its own operands, a repeated `into`) -- and each root expands the op that made it last.  An op
+// that refers to a cluster no earlier op made is the reference's HashMap index panic: APD_ERR_INVALID_ARG.  Nothing unwinds
+// across the C boundary: allocation failure (a degenerate op list can describe an exponentially large string) is APD_ERR_OOM.
 extern "C" int apd_dendrograms(const apd_cluster_op *ops, uint32_t n_ops, const uint32_t *roots, uint32_t n_roots,
                                const char *const *labels, uint32_t n_labels, char *out, uint64_t capacity, uint64_t *n_bytes,
                                uint32_t *which_root, uint32_t *n_strings)
 {
     if ((n_ops && !ops) || (n_roots && !roots) || !n_bytes || !n_strings || (n_labels && !labels)) return APD_ERR_INVALID_ARG;
-    // the op that made a node id (later ops overwrite earlier ones, as HashMap::insert does)
-    uint32_t max_id = 0;
-    for (uint32_t t = 0; t < n_ops; ++t) max_id = std::max(max_id, ops[t].into);
-    std::vector<int64_t> made((size_t)max_id + 1, -1);
-    // validate in replay order: a cluster operand must exist when its op runs (reporting.rs:154,158,163-164)
-    for (uint32_t t = 0; t < n_ops; ++t) {
-        const apd_cluster_op &o = ops[t];
-        const bool ci = o.operation == APD_CLUSTER2SEQUENCE || o.operation == APD_CLUSTER2CLUSTER;
-        const bool cj = o.operation == APD_SEQUENCE2CLUSTER || o.operation == APD_CLUSTER2CLUSTER;
-        if (o.operation > APD_CLUSTER2CLUSTER) return APD_ERR_INVALID_ARG;
-        if (ci ? (o.merge_i > max_id || made[o.merge_i] < 0) : o.merge_i >= n_labels) return APD_ERR_INVALID_ARG;
-        if (cj ? (o.merge_j > max_id || made[o.merge_j] < 0) : o.merge_j >= n_labels) return APD_ERR_INVALID_ARG;
-        made[o.into] = t;
-    }
-    // The string of a node is a function of the op that made it AT THAT TIME; ids are unique in a clustering run
-    // (into = n + t), so the final `made` table is the replay-time table.
-    std::string all;
-    uint32_t count = 0;
-    for (uint32_t r = 0; r < n_roots; ++r) {
-        const uint32_t id = roots[r];
-        if (id > max_id || made[id] < 0) continue;                               // "Cluster not found ... Singular cluster" (:200)
-        std::string s;
-        // iterative expansion: a stack of (op index, stage)
-        struct Frame { uint32_t op; int stage; };
-        std::vector<Frame> stack{{(uint32_t)made[id], 0}};
-        while (!stack.empty()) {
-            Frame &f = stack.back();
-            const apd_cluster_op &o = ops[f.op];
+    constexpr size_t kMaxBytes = (size_t)1 << 30;                                // refuse to build more than 1 GiB of brackets
+    try {
+        std::unordered_map<uint32_t, uint32_t> made;                             // node id -> op that made it last (ids are any u32)
+        std::vector<int64_t> src_i(n_ops, -1), src_j(n_ops, -1);                 // op that had made the cluster operand when op t ran
+        for (uint32_t t = 0; t < n_ops; ++t) {                                   // replay order (reporting.rs:143)
+            const apd_cluster_op &o = ops[t];
+            if (o.operation > APD_CLUSTER2CLUSTER) return APD_ERR_INVALID_ARG;
             const bool ci = o.operation == APD_CLUSTER2SEQUENCE || o.operation == APD_CLUSTER2CLUSTER;
             const bool cj = o.operation == APD_SEQUENCE2CLUSTER || o.operation == APD_CLUSTER2CLUSTER;
-            if (f.stage == 0) {
-                s += "[." + std::to_string(o.into) + " [";
-                f.stage = 1;
-                if (ci) { stack.push_back({(uint32_t)made[o.merge_i], 0}); continue; }
-                s += labels[o.merge_i];
-            }
-            if (f.stage == 1) {
-                s += " ";
-                f.stage = 2;
-                if (cj) { stack.push_back({(uint32_t)made[o.merge_j], 0}); continue; }
-                s += labels[o.merge_j];
-            }
-            s += " ] ]";
-            stack.pop_back();
+            if (ci) {
+                const auto it = made.find(o.merge_i);
+                if (it == made.end()) return APD_ERR_INVALID_ARG;                // results[&i] panics (:158, :164)
+                src_i[t] = it->second;
+            } else if (o.merge_i >= n_labels) return APD_ERR_INVALID_ARG;        // images[i] panics (:149, :154)
+            if (cj) {
+                const auto it = made.find(o.merge_j);
+                if (it == made.end()) return APD_ERR_INVALID_ARG;
+                src_j[t] = it->second;
+            } else if (o.merge_j >= n_labels) return APD_ERR_INVALID_ARG;
+            made[o.into] = t;                                                    // HashMap::insert (:151, :156, :161, :166)
         }
-        if (which_root && count < n_roots) which_root[count] = r;
-        all += s;
-        all.push_back('\0');
-        ++count;
+        std::string all;
+        uint32_t count = 0;
+        for (uint32_t r = 0; r < n_roots; ++r) {
+            const auto root = made.find(roots[r]);
+            if (root == made.end()) continue;                                    // "Cluster not found ... Singular cluster" (:200)
+            struct Frame { uint32_t op; int stage; };
+            std::vector<Frame> stack{{root->second, 0}};
+            while (!stack.empty()) {
+                Frame &f = stack.back();
+                const apd_cluster_op &o = ops[f.op];
+                if (f.stage == 0) {
+                    all += "[." + std::to_string(o.into) + " [";
+                    f.stage = 1;
+                    if (src_i[f.op] >= 0) { const uint32_t next = (uint32_t)src_i[f.op]; stack.push_back({next, 0}); continue; }
+                    all += labels[o.merge_i];
+                }
+                if (f.stage == 1) {
+                    all += " ";
+                    f.stage = 2;
+                    if (src_j[f.op] >= 0) { const uint32_t next = (uint32_t)src_j[f.op]; stack.push_back({next, 0}); continue; }
+                    all += labels[o.merge_j];
+                }
+                all += " ] ]";
+                stack.pop_back();
+                if (all.size() > kMaxBytes) return APD_ERR_OOM;
+            }
+            if (which_root && count < n_roots) which_root[count] = r;
+            all.push_back('\0');
+            ++count;
+        }
+        *n_bytes = all.size();
+        *n_strings = count;
+        if (!out) return APD_OK;                                                 // size query
+        if (capacity < all.size()) return APD_ERR_INVALID_ARG;
+        std::memcpy(out, all.data(), all.size());
+        return APD_OK;
+    } catch (const std::bad_alloc &) {
+        return APD_ERR_OOM;
+    } catch (...) {
+        return APD_ERR_INVALID_ARG;
     }
-    *n_bytes = all.size();
-    *n_strings = count;
-    if (!out) return APD_OK;                                                     // size query
-    if (capacity < all.size()) return APD_ERR_INVALID_ARG;
-    std::memcpy(out, all.data(), all.size());
-    return APD_OK;
 }

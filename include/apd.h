@@ -320,7 +320,8 @@ int apd_autoencoder_serialize(const float *w_encode, const float *w_decode, cons
                               uint32_t d_in, uint32_t latent, void *out, uint64_t capacity, uint64_t *n_bytes);
 
 /* Discovery (src/discovery.rs:7-26) and Discovery::from_toml (:28-36) on the text of project/config/Discovery.toml: flat
- * `key = value  # comment` lines; every field exactly once, unknown keys refused, integers for the usize fields. */
+ * `key = value  # comment` lines; every field exactly once, integers for the usize fields; keys the struct does not have
+ * (and anything under a [table] header) are ignored, as serde does without deny_unknown_fields. */
 typedef struct apd_discovery {
     uint64_t dft_win, dft_step, ceps_filter, vat_moving;
     float vat_percentile;
@@ -337,7 +338,9 @@ int apd_discovery_parse_toml(const char *text, apd_discovery *out);
  * bracket string "[.k [<left> <right> ] ]" with leaves rendered as labels[leaf] (the reference puts its image_ref there,
  * reporting.rs:211-221) -- NUL-terminated, concatenated in the order of `roots`; which_root[i] = index into roots of
  * string i (roots never merged have none, reporting.rs:200).  out == NULL: sizes only.  The LaTeX / file output of :171-203
- * is presentation and stays with the caller. */
+ * is presentation and stays with the caller.  Replay semantics are the reference's HashMap's for ANY ids (a repeated `into`
+ * overwrites, an op may name its own `into` as an operand: the string built earlier is embedded); a string beyond 1 GiB or an
+ * allocation failure is APD_ERR_OOM, never an abort. */
 int apd_dendrograms(const apd_cluster_op *ops, uint32_t n_ops, const uint32_t *roots, uint32_t n_roots,
                     const char *const *labels, uint32_t n_labels, char *out, uint64_t capacity, uint64_t *n_bytes,
                     uint32_t *which_root, uint32_t *n_strings);

@@ -86,13 +86,21 @@ clustering_percentile   = 0.05
     assert (d.learning_rate, d.epoch_drop, d.drop) == (np.float32(0.1), 5.0, 0.5)
     for bad in ("dft_win = 1\n",                                        # 16 fields missing (serde: missing field)
                 text + "dft_win = 3\n",                                  # duplicate key
-                text + "colour = 3\n",                                   # unknown key
                 text.replace("dft_step      = 128", "dft_step      = 128.5"),   # a float where usize is wanted
                 text.replace("epochs        = 25", "epochs        = -25"),
                 text.replace("drop          = 0.5", "drop          = half")):
         (tmp_path / "bad.toml").write_text(bad)
         with pytest.raises(KeyError):
             Discovery.from_toml(str(tmp_path / "bad.toml"))
+    # keys the struct does not have are IGNORED: `#[derive(Deserialize)] struct Discovery` (discovery.rs:7) has no
+    # deny_unknown_fields, so toml::from_str accepts them -- and a [table] hides what follows it from the top-level fields
+    for extra in (text + "colour = 3\n", "note = \"a string\"\n" + text, text + "[plots]\ndft_win = 7\nwidth = 3\n"):
+        (tmp_path / "extra.toml").write_text(extra)
+        e = Discovery.from_toml(str(tmp_path / "extra.toml"))
+        assert (e.dft_win, e.alignment_workers, e.warping_band_percentage) == (256, 4, 0.0625)
+    (tmp_path / "bad.toml").write_text(text + "colour\n")                   # not `key = value`
+    with pytest.raises(KeyError):
+        Discovery.from_toml(str(tmp_path / "bad.toml"))
     # the file the reference ships parses (project/config/Discovery.toml, reproduced in SURVEY.md section 5: band 1.0, workers 4)
     (tmp_path / "shipped.toml").write_text(text.replace("0.0625", "1.0       # sakoe shiba band"))
     assert Discovery.from_toml(str(tmp_path / "shipped.toml")).warping_band_percentage == 1.0
@@ -184,6 +192,27 @@ def test_dendrograms_equal_a_literal_replay_of_the_reference_loop(oracle, apd):
         want = {r: results[r] for r in roots if r in results}
         mine = [ClusteringOperation(o["merge_i"], o["merge_j"], o["into"], o["distance"], Merge[o["operation"]]) for o in ops]
         assert dendrograms(mine, set(roots), labels) == want
+    # ids need not be unique or fresh: HashMap::insert overwrites, a string built earlier keeps its operands by value.  An op
+    # whose `into` is one of its own operands, a repeated `into`, a huge id -- all finite, all equal to the literal replay.
+    S2S, S2C, C2S, C2C = Merge.Sequence2Sequence, Merge.Sequence2Cluster, Merge.Cluster2Sequence, Merge.Cluster2Cluster
+    odd = [[ClusteringOperation(0, 1, 5, 0.1, S2S), ClusteringOperation(5, 2, 5, 0.2, C2S)],
+           [ClusteringOperation(0, 1, 5, 0.1, S2S), ClusteringOperation(2, 3, 5, 0.2, S2S), ClusteringOperation(5, 5, 6, 0.3, C2C)],
+           [ClusteringOperation(0, 1, 4000000000, 0.1, S2S), ClusteringOperation(2, 4000000000, 7, 0.2, S2C), ClusteringOperation(7, 7, 7, 0.3, C2C),
+            ClusteringOperation(7, 3, 4000000000, 0.3, C2S)]]
+    labels = ["a", "b", "c", "d"]
+    for ops in odd:
+        results = {}
+        for o in ops:
+            left = results[o.merge_i] if o.operation in (C2S, C2C) else labels[o.merge_i]
+            right = results[o.merge_j] if o.operation in (S2C, C2C) else labels[o.merge_j]
+            results[o.into] = "[.%d [%s %s ] ]" % (o.into, left, right)
+        assert dendrograms(ops, set(results), labels) == results
+    assert dendrograms(odd[0], {5}, labels) == {5: "[.5 [[.5 [a b ] ] c ] ]"}
+    # a degenerate list can describe an exponentially large string (every op doubles the last one): refused with OOM, not an abort
+    doubling = [ClusteringOperation(0, 1, 4, 0.1, S2S)] + [ClusteringOperation(3 + t, 3 + t, 4 + t, 0.1, C2C) for t in range(1, 40)]
+    with pytest.raises(apd.ApdError) as e:
+        dendrograms(doubling, {43}, labels)
+    assert e.value.status == apd.APD_ERR_OOM
     # an op that names a cluster no earlier op made: the reference's HashMap index panics
     with pytest.raises(apd.ApdError):
         dendrograms([ClusteringOperation(0, 7, 4, 0.1, Merge.Sequence2Cluster)], {4}, ["A", "B"])
@@ -204,3 +233,18 @@ def test_bench_gpus_n_starts_in_process():
                          capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert out.returncode != 0
     assert "torch.distributed.run" not in out.stderr and "no gfx950 HIP device" in out.stderr, out.stderr[-1500:]
+
+
+def test_formats_survive_the_sanitizer_fuzz(tmp_path):
+    """csrc/formats.hip is host-only: built as plain C++ under AddressSanitizer + UBSan (CPU build: the pool has no GPU sanitizer)
+    and fed random / mutated op lists (repeated ids, self references), Discovery.toml texts and bincode images."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fuzz_formats")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-x", "c++",
+                           os.path.join(root, "tools", "fuzz", "fuzz_formats.cpp"), "-o", exe])
+    out = subprocess.run([exe, "20000", "99"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "no sanitizer report" in out.stdout, out.stdout[-1000:] + out.stderr[-3000:]
