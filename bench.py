@@ -54,6 +54,8 @@ WORKLOADS = {
 }
 WORKLOADS["cfg5s"] = dict(n_seq=512, length=2048, dim=13, pct=0.0625,
                           desc="512 seq len~2048 D=13, band=128 (cfg 5's per-pair shape at 1/32 of its sequence count; not a BASELINE config)")
+WORKLOADS["cfg5m"] = dict(n_seq=2048, length=2048, dim=13, pct=0.0625,
+                          desc="2048 seq len~2048 D=13, band=128 (cfg 5's per-pair shape at 1/8 of its sequence count: 1000 waves per SIMD slot instead of cfg5s' 33; not a BASELINE config)")
 WORKLOADS["cfg5e"] = dict(n_seq=256, length=2048, dim=13, pct=0.0625, audio=True,
                           desc="cfg 5's end-to-end data path at 1/64 of its sequence count: 256 recordings x 262400 i16 samples -> on-device "
                                "cepstrum (spectrogram.rs:31-80, dft_win 256, step 128, ceps_filter 18 -> 13 bins) -> DTW band=128 (not a BASELINE config)")

@@ -189,7 +189,11 @@ class AlignmentWorkers {
         if (dim == 0) dim = 1;
         check(apd_batch_create(ctx_.get(), frames.data(), offsets.data(), (uint32_t)n, dim, 0, &batch_), ctx_.get());
     }
-    ~AlignmentWorkers() { if (batch_) apd_batch_destroy(batch_); }
+    ~AlignmentWorkers()
+    {
+        if (multi_) apd_multi_destroy(multi_);                                       // also destroys its batch
+        if (batch_) apd_batch_destroy(batch_);
+    }
     AlignmentWorkers(const AlignmentWorkers &) = delete;
     AlignmentWorkers &operator=(const AlignmentWorkers &) = delete;
     void align_all(const Discovery &params)                                          // :31-67, blocking
@@ -198,20 +202,34 @@ class AlignmentWorkers {
         check(apd_align_all(ctx_.get(), batch_, &c, result.data()), ctx_.get());
     }
     // The same over several GPUs of one node (the reference's `alignment_workers` threads, alignments.rs:33-41, become devices):
-    // pair tiles sharded over `devices`, one RCCL all-gather inside the library.  Returns the ranks RCCL saw.
+    // pair tiles sharded over `devices`, one RCCL all-gather inside the library.  The multi-device handle (contexts,
+    // communicators, worker threads, the corpus resident on every device) is made on the first call and kept: a host that calls
+    // align_all in a loop (main.rs:187-195) pays setup once.  Returns the ranks RCCL saw.
     uint32_t align_all(const Discovery &params, const std::vector<int> &devices)
     {
         const apd_align_config c = params.config();
+        if (multi_ && devices != multi_devices_) { apd_multi_destroy(multi_); multi_ = nullptr; multi_batch_ = nullptr; }
+        if (!multi_) {
+            check(apd_multi_create(devices.data(), (uint32_t)devices.size(), &multi_));
+            multi_devices_ = devices;
+            const int rc = apd_multi_batch_create(multi_, frames.data(), nullptr, offsets.data(), (uint32_t)data.size(), dim, &multi_batch_);
+            if (rc != APD_OK) throw Error(rc, std::string(apd_status_string(rc)) + ": " + apd_multi_last_error(multi_));
+        }
+        const int rc = apd_multi_align_all(multi_, multi_batch_, &c, result.data());
+        if (rc != APD_OK) throw Error(rc, std::string(apd_status_string(rc)) + ": " + apd_multi_last_error(multi_));
         uint32_t seen = 0;
-        check(apd_align_all_multi(devices.data(), (uint32_t)devices.size(), frames.data(), offsets.data(), (uint32_t)data.size(), dim, &c,
-                                  result.data(), &seen));
+        check(apd_multi_ranks_seen(multi_, &seen));
         return seen;
     }
+    const char *collective() const { return multi_ ? apd_multi_collective(multi_) : "none (one device)"; }
     std::vector<NDSequence> data;
     std::vector<float> result;                                                       // n*n row-major, diagonal 0.0
   private:
     Context &ctx_;
     apd_batch *batch_ = nullptr;
+    apd_multi *multi_ = nullptr;                                                     // made by the first multi-device align_all
+    apd_multi_batch *multi_batch_ = nullptr;
+    std::vector<int> multi_devices_;
     std::vector<float> frames;                                                       // packed [sum len][dim], kept for the multi-device entry
     std::vector<uint64_t> offsets;
     uint32_t dim = 1;

@@ -57,6 +57,9 @@ int main(int argc, char **argv)
             const std::vector<float> single = workers.result;
             const uint32_t seen = workers.align_all(cfg, std::vector<int>{0});
             std::printf("multi %u %d\n", seen, (int)(std::memcmp(single.data(), workers.result.data(), single.size() * sizeof(float)) == 0));
+            workers.align_all(cfg, std::vector<int>{0});                                  // the handle is kept: second call, same bits
+            std::printf("multi_again %d %s\n", (int)(std::memcmp(single.data(), workers.result.data(), single.size() * sizeof(float)) == 0),
+                        std::strncmp(workers.collective(), "rccl", 4) == 0 ? "rccl" : workers.collective());
         }
         auto res = apd::AgglomerativeClustering::clustering(ctx, workers.result, n, cfg.clustering_percentile);
         for (const auto &o : res.first) std::printf("op %zu %zu %zu %.9g %d\n", o.merge_i, o.merge_j, o.into, o.distance, (int)o.operation);

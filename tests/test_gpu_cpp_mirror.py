@@ -37,7 +37,8 @@ def test_cpp_mirror_end_to_end(oracle, tmp_path):
     assert sets == oracle.cluster_sets(ops, roots, n)
     pair = float([l for l in lines if l.startswith("pair01")][0].split()[1])
     assert abs(pair - want[0, 1]) <= 1e-4 * want[0, 1]
-    assert [l for l in lines if l.startswith("multi")][0].split()[1:] == ["1", "1"]      # apd_align_all_multi({0}): one rank, same bits
+    assert [l for l in lines if l.startswith("multi ")][0].split()[1:] == ["1", "1"]     # the multi-device handle on {0}: one rank, same bits
+    assert [l for l in lines if l.startswith("multi_again")][0].split()[1:] == ["1", "rccl"]   # kept handle, second call, RCCL collective
 
 
 def test_cpp_mirror_with_the_references_on_disk_artefacts(oracle, tmp_path):
