@@ -154,6 +154,13 @@ uint32_t apd_tile_size(void);
 uint64_t apd_num_tiles(uint32_t n_seq);
 uint64_t apd_rank_tiles(uint32_t n_seq, uint32_t rank, uint32_t world);
 uint64_t apd_slab_floats(uint32_t n_seq, uint32_t world);
+/* "_async" for the alignment entry points (this one, apd_align_all_device_async, apd_align_all_sharded_async,
+ * apd_multi_align_all_async) means: the kernels, the collective and the unpack are only ENQUEUED when the call returns.  One
+ * host-side wait is inside them all the same: the first alignment after apd_batch_create / apd_batch_refill reads the repack
+ * kernel's verdict on non-finite frames back (4 bytes D2H and a synchronisation of the context's stream) before it chooses
+ * between the fast kernels and the literal, NaN-faithful one; later alignments of the same fill do not wait.  Consequences:
+ * not usable inside a stream capture; a pipeline that refills every step is host-serialised with the previous step's
+ * kernels (the GPU does not idle for it: the wait ends when the stream is empty, and the launches follow at once). */
 int apd_align_tiles_async(apd_context *ctx, const apd_batch *batch, const apd_align_config *cfg,
                           uint32_t rank, uint32_t world, float *d_slab);
 int apd_unpack_tiles_async(apd_context *ctx, const apd_batch *batch, uint32_t world, const float *d_gathered,

@@ -248,3 +248,22 @@ def test_formats_survive_the_sanitizer_fuzz(tmp_path):
                            os.path.join(root, "tools", "fuzz", "fuzz_formats.cpp"), "-o", exe])
     out = subprocess.run([exe, "20000", "99"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "no sanitizer report" in out.stdout, out.stdout[-1000:] + out.stderr[-3000:]
+
+
+def test_rust_binding_declares_every_symbol_with_the_headers_arity():
+    """bindings/rust/src/apd_sys.rs cannot be compiled here (no rustc), so it is at least kept in step with include/apd.h
+    mechanically: the same set of functions, each with as many parameters as the C declaration."""
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "apd.h")).read(), flags=re.S)
+    c_decl = {m.group(1): m.group(2) for m in re.finditer(r"\b(apd_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S)}
+    rust = open(os.path.join(ROOT, "bindings", "rust", "src", "apd_sys.rs")).read()
+    rust = re.sub(r"//.*", "", rust)
+    r_decl = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (apd_[a-z0-9_]+)\s*\(([^)]*)\)", rust, flags=re.S)}
+    assert set(c_decl) == set(declared_symbols())
+    assert set(r_decl) == set(c_decl), "apd_sys.rs and apd.h disagree: %s" % sorted(set(r_decl) ^ set(c_decl))
+
+    def arity(params):
+        params = params.strip()
+        return 0 if params in ("", "void") else params.count(",") + 1
+
+    for name in c_decl:
+        assert arity(c_decl[name]) == arity(r_decl[name]), "%s: %d parameters in apd.h, %d in apd_sys.rs" % (name, arity(c_decl[name]), arity(r_decl[name]))
