@@ -282,9 +282,14 @@ extern "C" int apd_multi_create(const int *devices, uint32_t n_devices, apd_mult
 {
     if (!devices || n_devices == 0 || !out) return APD_ERR_INVALID_ARG;
     *out = nullptr;
-    for (uint32_t i = 0; i < n_devices; ++i)
+    const char *force = std::getenv("APD_MULTI_COLLECTIVE");
+    const bool force_peer = force && std::strcmp(force, "peer") == 0;
+    // RCCL refuses two ranks on one device.  The peer-copy collective does not care: with it forced, a device may be named more
+    // than once -- several "ranks" (contexts, streams, worker threads, tile shares, slabs) on one GPU.  That is how the N > 1
+    // machinery of this handle is rehearsed on a box with a single GPU (tests/test_gpu_multi.py); it is of no use in production.
+    for (uint32_t i = 0; i < n_devices && !force_peer; ++i)
         for (uint32_t j = 0; j < i; ++j)
-            if (devices[i] == devices[j]) return APD_ERR_INVALID_ARG;        // RCCL refuses two ranks on one device
+            if (devices[i] == devices[j]) return APD_ERR_INVALID_ARG;
     apd_multi *m = new (std::nothrow) apd_multi();
     if (!m) return APD_ERR_OOM;
     m->devices.assign(devices, devices + n_devices);
@@ -292,9 +297,8 @@ extern "C" int apd_multi_create(const int *devices, uint32_t n_devices, apd_mult
     int rc = APD_OK;
     for (uint32_t i = 0; i < n_devices && rc == APD_OK; ++i) rc = apd_create(devices[i], &m->ctx[i]);
     if (rc != APD_OK) { apd_multi_destroy(m); return rc; }
-    const char *force = std::getenv("APD_MULTI_COLLECTIVE");
     std::string why;
-    if (force && std::strcmp(force, "peer") == 0) why = "APD_MULTI_COLLECTIVE=peer";
+    if (force_peer) why = "APD_MULTI_COLLECTIVE=peer";
     else {
         m->comms.assign(n_devices, nullptr);
         const ncclResult_t r = ncclCommInitAll(m->comms.data(), (int)n_devices, devices);

@@ -407,8 +407,11 @@ def main():
     collective, collective_fallback, collective_error, ranks_seen = "none (1 rank)", False, None, 1
     dist = torch = nccl_group = None
     if multi_mode:
-        first = int(os.environ.get("APD_FIRST_DEVICE", "0"))
-        multi = sharding.Multi(list(range(first, first + world)))
+        # APD_BENCH_DEVICES=0,0,0,0 (with APD_MULTI_COLLECTIVE=peer): rehearse N ranks of the handle on ONE GPU; not a measurement
+        dev_list = [int(v) for v in os.environ["APD_BENCH_DEVICES"].split(",")] if os.environ.get("APD_BENCH_DEVICES") else list(range(world))
+        if len(dev_list) != world:
+            raise SystemExit("APD_BENCH_DEVICES must name --gpus devices")
+        multi = sharding.Multi(dev_list)
         ctxs = multi.contexts
         collective, ranks_seen = "apd_multi: " + multi.collective(), multi.ranks_seen()
         collective_fallback = multi.collective().startswith("peer-copy")

@@ -206,7 +206,8 @@ int apd_align_all_multi(const int *devices, uint32_t n_devices, const float *fra
  * all-gather + unpack only.
  * If RCCL cannot make the communicators (or APD_MULTI_COLLECTIVE=peer is set), the handle falls back to gathering the slabs
  * onto devices[0] with hipMemcpyPeerAsync; apd_multi_collective() says which and carries RCCL's error text.  Results are
- * the same bits either way (the collective only moves the slabs). */
+ * the same bits either way (the collective only moves the slabs).  With the peer-copy collective forced a device may be named
+ * several times in `devices` (several ranks on one GPU): a rehearsal aid for single-GPU boxes, nothing else. */
 typedef struct apd_multi apd_multi;
 typedef struct apd_multi_batch apd_multi_batch;
 int apd_multi_create(const int *devices, uint32_t n_devices, apd_multi **multi);

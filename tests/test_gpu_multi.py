@@ -134,3 +134,42 @@ def test_one_shot_entry_point_is_the_handle(apd, oracle):
     got, seen = sharding.align_all_multi([0], frames, offsets, 8, cfg)
     assert seen == 1
     assert_parity(got, oracle.align_all(frames, offsets, 0.25, workers=8))
+
+
+def test_several_ranks_on_one_gpu_through_the_peer_collective(apd, oracle):
+    """The N > 1 machinery of the handle -- one worker thread, context, stream, tile share and slab per rank, the cross-stream
+    ordering of the gather, the world-N unpack -- rehearsed on ONE GPU: with the peer-copy collective forced a device may be
+    named several times (RCCL itself refuses two ranks on a device).  3 and 8 ranks, repeated calls, a refill in between: every
+    matrix bitwise equal to the one-rank result."""
+    from audio_pattern_discovery_amd import sharding
+    n = 150
+    f1, offsets = synth.make_sequences(n, 90, 13, seed=31, jitter=20)
+    f2 = (f1 * np.float32(1.25) + np.float32(0.5)).astype(np.float32)
+    cfg = apd.AlignConfig(0.0625, 1.0, 1.0, 1.0)
+    one = sharding.Multi([0])
+    ob = one.batch(offsets, 13, frames=f1)
+    want1 = one.align_all(ob, cfg)
+    ob.refill(frames=f2)
+    want2 = one.align_all(ob, cfg)
+    one.close()
+    assert not np.array_equal(want1, want2)
+    os.environ["APD_MULTI_COLLECTIVE"] = "peer"
+    try:
+        for world in (3, 8):
+            m = sharding.Multi([0] * world)
+            assert m.ranks_seen() == world and len(m.contexts) == world
+            mb = m.batch(offsets, 13, frames=f1)
+            for _ in range(3):
+                assert np.array_equal(m.align_all(mb, cfg).view(np.uint32), want1.view(np.uint32))
+            mb.refill(frames=f2)
+            assert np.array_equal(m.align_all(mb, cfg).view(np.uint32), want2.view(np.uint32))
+            # asynchronous form back to back (the slab of a rank must not be poisoned again before rank 0 has copied it)
+            d_out = m.contexts[0].alloc(4 * n * n)
+            for _ in range(4):
+                m.align_all_async(mb, cfg, d_out.ptr)
+            m.synchronize()
+            assert np.array_equal(d_out.to_numpy(np.uint32).reshape(n, n), want2.view(np.uint32))
+            m.close()
+    finally:
+        del os.environ["APD_MULTI_COLLECTIVE"]
+    assert_parity(want1, oracle.align_all(f1, offsets, 0.0625, workers=8))
