@@ -443,6 +443,7 @@ extern "C" int apd_multi_align_all_async(apd_multi *m, const apd_multi_batch *mb
         ncclResult_t r = ncclGroupStart();
         for (uint32_t i = 0; i < n && r == ncclSuccess; ++i) {
             float *g = (float *)m->ctx[i]->ws_gather;
+            hipSetDevice(m->ctx[i]->device);
             r = ncclAllGather(g + (size_t)slab * i, g, (size_t)slab, ncclFloat, m->comms[i], m->ctx[i]->stream);
         }
         const ncclResult_t r2 = ncclGroupEnd();

@@ -173,3 +173,24 @@ def test_several_ranks_on_one_gpu_through_the_peer_collective(apd, oracle):
     finally:
         del os.environ["APD_MULTI_COLLECTIVE"]
     assert_parity(want1, oracle.align_all(f1, offsets, 0.0625, workers=8))
+
+
+def test_more_ranks_than_tiles_and_degenerate_batches(apd, oracle):
+    """24 sequences are 3 pair tiles: with 8 ranks five of them own nothing (their slabs stay poisoned and are never read);
+    one sequence is a 1 x 1 zero matrix; an empty batch is a no-op."""
+    from audio_pattern_discovery_amd import sharding
+    cfg = apd.AlignConfig(1.0, 1.0, 1.0, 1.0)
+    os.environ["APD_MULTI_COLLECTIVE"] = "peer"
+    try:
+        m = sharding.Multi([0] * 8)
+    finally:
+        del os.environ["APD_MULTI_COLLECTIVE"]
+    frames, offsets = synth.make_sequences(24, 40, 13, seed=8)
+    got = m.align_all(m.batch(offsets, 13, frames=frames), cfg)
+    want = oracle.align_all(frames, offsets, 1.0, workers=8)
+    assert_parity(got, want)
+    one = m.align_all(m.batch(offsets[:2], 13, frames=frames[:int(offsets[1])]), cfg)
+    assert one.shape == (1, 1) and one[0, 0] == 0.0
+    empty = m.batch(np.zeros(1, np.uint64), 13, frames=np.zeros((0, 13), np.float32))
+    assert m.align_all(empty, cfg).shape == (0, 0)
+    m.close()
