@@ -2,7 +2,6 @@
 usage: python tools/debug/fuzz.py [n_cases] [seed]"""
 import sys, time, numpy as np
 sys.path.insert(0, ".")
-import torch  # noqa: F401  (loads the HIP runtime first)
 from audio_pattern_discovery_amd import synth, _lib
 from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
 from audio_pattern_discovery_amd.discovery import Discovery

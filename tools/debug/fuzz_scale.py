@@ -1,7 +1,6 @@
 """Hybrid-distance robustness sweep (run on the GPU box): feature scales, common offsets and mixed magnitudes."""
 import sys, numpy as np
 sys.path.insert(0, ".")
-import torch  # noqa: F401
 from audio_pattern_discovery_amd import synth, _lib
 from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
 from audio_pattern_discovery_amd.discovery import Discovery

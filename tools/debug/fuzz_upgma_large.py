@@ -5,7 +5,6 @@ to +INF), many exact zeros, negative entries, NaN / +INF entries, wide dynamic r
 usage (GPU box): python tools/debug/fuzz_upgma_large.py [n_cases] [seed]"""
 import sys, time, numpy as np
 sys.path.insert(0, ".")
-import torch  # noqa: F401
 from audio_pattern_discovery_amd import _lib
 from audio_pattern_discovery_amd.clustering import AgglomerativeClustering
 from oracle import binding as oracle

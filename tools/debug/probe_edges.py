@@ -1,7 +1,6 @@
 """Edge-case probes of the C ABI through the Python mirror (run on the GPU box)."""
 import sys, numpy as np
 sys.path.insert(0, ".")
-import torch  # noqa
 from audio_pattern_discovery_amd import _lib, synth
 from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
 from audio_pattern_discovery_amd.discovery import Discovery

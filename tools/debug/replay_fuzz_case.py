@@ -2,7 +2,6 @@
 usage: python tools/debug/replay_fuzz_case.py <seed> <case>"""
 import sys, numpy as np
 sys.path.insert(0, ".")
-import torch  # noqa: F401
 from audio_pattern_discovery_amd import synth, _lib
 from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
 from audio_pattern_discovery_amd.discovery import Discovery
