@@ -241,7 +241,8 @@ class Context:
 
     def set_distance_mode(self, mode, tau=0.0):
         """0 / "exact": difference form; 1 / "hybrid": norm expansion with exact recomputation below tau;
-        2 / "strict": the reference's arithmetic operation for operation (bit-identical scores, ~2.5x slower)."""
+        2 / "strict": the reference's arithmetic operation for operation in every kernel family (bit-identical scores, ~2x slower);
+        0 already is that on the band-form kernels."""
         mode = {"exact": 0, "hybrid": 1, "strict": 2}.get(mode, mode)
         check(lib().apd_set_distance_mode(self.handle, int(mode), float(tau)))
 

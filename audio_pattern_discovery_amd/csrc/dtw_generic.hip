@@ -395,7 +395,11 @@ static hipError_t launch_align_chunk(const AlignLaunch &L, int geom_key, hipStre
     *status = APD_OK;
     if (L.n_tiles == 0) return hipSuccess;
     const BandSpec &b = L.band;
-    const bool unit = (b.ins == 1.0f) && (b.del == 1.0f) && (b.mat == 1.0f) && !L.strict;   // the systolic kernel's UNIFORM_PEN path: no weighting at all
+    const bool unit_pens = (b.ins == 1.0f) && (b.del == 1.0f) && (b.mat == 1.0f);
+    // the systolic kernel's UNIFORM_PEN path (no weighting at all).  Strict mode keeps it: with unit penalties the fast select on
+    // the difference form -- which in the band kernels is the reference's arithmetic operation for operation -- gives the CPU
+    // code's bits (see dtw_systolic.h); only the hybrid distance form is switched off.
+    const bool unit = unit_pens;
     bool done = false;
     AlignLaunch LL = L;
     // The norm expansion trades D - 1 vector ops per cell (systolic kernel, pre-scaled rows; D - 4 in the strip kernels) for a
@@ -403,6 +407,7 @@ static hipError_t launch_align_chunk(const AlignLaunch &L, int geom_key, hipStre
     static const int hybrid_min_env = std::getenv("APD_HYBRID_MIN_DIM") ? std::atoi(std::getenv("APD_HYBRID_MIN_DIM")) : 0;   // tuning aid
     const int hybrid_min_dim = hybrid_min_env ? hybrid_min_env : (geom_key >= 100 && geom_key < 10000 ? 8 : 10);
     if ((int)LL.dim < hybrid_min_dim) LL.hybrid = 0;
+    if (L.strict && geom_key >= 100 && geom_key < 10000) LL.hybrid = 0;
     if (geom_key >= 20000) {
         const bool banded = geom_key >= 30000;
         const int nw = (geom_key % 10000) / 100, cw = geom_key % 100;

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     constexpr bool PIPE = (APD_ABLATE & 32) != 0;                  // measured: no gain on MI355X (cfg 3: -2 %), kept as a tuning switch
     float dn[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) dn[c] = (PIPE && !HYBRID && c < C - 1) ? frame_dist<D, DN>(xs[0], yf[c]) : 0.0f;
+    for (int c = 0; c < C; ++c) dn[c] = (PIPE && !HYBRID && c < C - 1) ? frame_dist_strict<D, DN>(xs[0], yf[c]) : 0.0f;
 
     // advance the column window: every column moves one lane down (q: position inside the unrolled block)
     auto advance_window = [&](int q) __attribute__((always_inline)) {
@@ -401,11 +401,14 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
                 } else {
 #pragma unroll
                     for (int c = 0; c < C; ++c)
-                        d[c] = !UNIFORM_PEN ? frame_dist_strict<D, DN>(xs[xa], yf[(r + c) % S])
-                                            : ((PIPE && c < C - 1) ? dn[c] : frame_dist<D, DN>(xs[xa], yf[(r + c) % S]));
+                        // The difference form of the band kernels IS the reference's arithmetic (numerics.rs:114-120 operation for
+                        // operation), with either select: with unit penalties `base + 1.0 * d` is `base + d` and the fast select
+                        // picks the reference's predecessor for every non-NaN input, so <.., UNIFORM_PEN = true, HYBRID = false> is
+                        // bit-identical to the CPU code at 4 instead of ~12 vector ops per node (strict mode, apd_set_distance_mode 2).
+                        d[c] = (UNIFORM_PEN && PIPE && c < C - 1) ? dn[c] : frame_dist_strict<D, DN>(xs[xa], yf[(r + c) % S]);
                     if (PIPE) {
 #pragma unroll
-                        for (int c = 0; c < C - 1; ++c) dn[c] = frame_dist<D, DN>(xs[xb], yf[(r + 1 + c) % S]);
+                        for (int c = 0; c < C - 1; ++c) dn[c] = frame_dist_strict<D, DN>(xs[xb], yf[(r + 1 + c) % S]);
                     }
                 }
                 // the two DP rows

@@ -92,20 +92,24 @@ float apd_last_kernel_ms(apd_context *ctx);
 /* Tuning knob for experiments: 0 = pick automatically.  See DESIGN.md "Kernel variants". */
 int apd_set_variant(apd_context *ctx, int variant);
 /* Local-distance form of the fast kernels with UNIT penalties (1.0, 1.0, 1.0 -- the shipped Discovery.toml).
- * mode 0: sqrt(sum (x_k-y_k)^2) as an fma chain, ~2e-7 relative of the reference.  mode 1 (default, D >= 8 in the band kernel, D >= 10 in the strip kernels):
- * |x|^2 + |y|^2 - 2 x.y from precomputed frame norms, recomputed in the difference form wherever the result is below
- * tau * (|x|^2 + |y|^2) (cancellation region; tau <= 0 keeps the current value, default 1/64): 9 fewer vector ops
- * per cell, ~3e-7 relative measured (tolerance asked: 1e-4); exact copies score exactly 0 in both.
- * With any other penalties the recurrence is discontinuous in its inputs (the penalty added depends on which
- * predecessor wins a strict comparison), so the library ignores the mode and computes operation for operation as
- * numerics.rs:114-120 / alignments.rs:129-160 do: results are then bit-identical to the CPU arithmetic.
- * mode 2 (strict): that operation-for-operation arithmetic for unit penalties as well -- every score bit-identical to the
- * CPU code, about 2.5x slower.  What it buys over modes 0 / 1: the reference resolves an EXACT tie between the DELETE and
- * INSERT predecessors by taking MATCH even when MATCH is larger; when such a tie arises by coincidence of two rounded
- * f32 sums (real-valued features: about one matrix entry in 5 million on short sequences, tools/debug/fuzz.py), modes 0 / 1
- * -- whose distances differ in the last bit -- do not see a tie and keep the smaller predecessor, and that one entry can
- * differ by a few 1e-4 relative.  Ties that are structural (identical frames, integer features, +INF) are reproduced in
- * every mode. */
+ * mode 1 (default; D >= 8 in the band kernels, D >= 10 in the strip kernels): |x|^2 + |y|^2 - 2 x.y from precomputed frame
+ * norms, recomputed in the difference form wherever the result is below tau * (|x|^2 + |y|^2) (cancellation region; tau <= 0
+ * keeps the current value, default 1/64): ~3e-7 relative measured (tolerance asked: 1e-4); exact copies score exactly 0.
+ * mode 0: the difference form sqrt(sum (x_k-y_k)^2).  In the band-form kernels it is computed operation for operation as
+ * numerics.rs:114-120 does (every difference, square and partial sum rounded on its own, correctly rounded sqrt), and with
+ * unit penalties the fast select picks the reference's predecessor for every non-NaN input: scores are bit-identical to the CPU
+ * code, about 2x the time of mode 1.  (The strip kernels of full-band batches keep an fma chain in mode 0: ~2e-7.)
+ * mode 2 (strict): the reference's arithmetic in EVERY kernel family -- band kernels as mode 0, strip kernels through their
+ * literal-select path: every score bit-identical to the CPU code.  cfg 3: 1.58 s instead of 0.76 s.
+ * With any other penalties the recurrence is discontinuous in its inputs (the penalty added depends on which predecessor wins
+ * a strict comparison), so the library ignores the mode and computes operation for operation as numerics.rs:114-120 /
+ * alignments.rs:129-160 do: bit-identical to the CPU arithmetic.
+ * What modes 0 / 2 buy over mode 1: the reference resolves an EXACT tie between the DELETE and INSERT predecessors by taking
+ * MATCH even when MATCH is larger; when such a tie arises by coincidence of two rounded f32 sums (real-valued features),
+ * mode 1 -- whose distances differ in the last bit -- does not see a tie and keeps the smaller predecessor, and that entry can
+ * differ by a few 1e-4 relative.  Counted over every entry of the BASELINE shapes (tests/test_gpu_census.py): none on cfg 2,
+ * cfg 3 and cfg 5's shape, one pair of 8.4 million on cfg 4.  Ties that are structural (identical frames, integer features,
+ * +INF) are reproduced in every mode. */
 int apd_set_distance_mode(apd_context *ctx, int mode, float tau);
 /* Device self-test of the cross-lane primitives the kernels rely on (DPP wave shifts). */
 int apd_selftest(apd_context *ctx);
