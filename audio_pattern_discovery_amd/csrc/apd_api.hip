@@ -134,6 +134,8 @@ extern "C" int apd_destroy(apd_context *ctx)
     ctx->batches.clear();
     for (apd_comm *c : ctx->comms) apd::orphan_comm(c);
     ctx->comms.clear();
+    for (void *p : ctx->buffers) hipFree(p);                              // apd_device_alloc'ed and never freed
+    ctx->buffers.clear();
     if (ctx->ws_tiles) hipFree(ctx->ws_tiles);
     if (ctx->ws_slab) hipFree(ctx->ws_slab);
     if (ctx->ws_misc) hipFree(ctx->ws_misc);
@@ -779,6 +781,7 @@ extern "C" int apd_device_alloc(apd_context *ctx, uint64_t bytes, void **d_ptr)
     *d_ptr = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMalloc(d_ptr, std::max<size_t>((size_t)bytes, 16)));
+    ctx->buffers.insert(*d_ptr);
     return APD_OK;
 }
 
@@ -787,6 +790,7 @@ extern "C" int apd_device_free(apd_context *ctx, void *d_ptr)
     if (!ctx) return APD_ERR_INVALID_ARG;
     if (!d_ptr) return APD_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->buffers.erase(d_ptr) == 0) return APD_ERR_INVALID_ARG;       // not a buffer of this context (or freed twice)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                      // nothing queued may still use it
     HIP_TRY(ctx, hipFree(d_ptr));
     return APD_OK;

@@ -117,6 +117,10 @@ struct apd_context {
     // communicators made on this context and not yet destroyed: apd_destroy tears their RCCL side down and orphans them, so
     // that a later apd_comm_destroy only frees the host part (same contract as for batches)
     std::set<apd_comm *> comms;
+    // buffers handed out by apd_device_alloc and not yet freed: apd_destroy releases them (a host whose destructors run in any
+    // order -- a garbage collector's -- may free a buffer after its context: apd_device_free on a destroyed context is never
+    // called by the mirrors, and nothing leaks)
+    std::set<void *> buffers;
     bool timed = false;
     int variant = 0;
     int distance_mode = 1;            // 0 exact differences, 1 hybrid, 2 strict (bit-identical to the CPU arithmetic)

@@ -212,6 +212,8 @@ int apd_align_all_multi(const int *devices, uint32_t n_devices, const float *fra
  * onto devices[0] with hipMemcpyPeerAsync; apd_multi_collective() says which and carries RCCL's error text.  Results are
  * the same bits either way (the collective only moves the slabs).  With the peer-copy collective forced a device may be named
  * several times in `devices` (several ranks on one GPU): a rehearsal aid for single-GPU boxes, nothing else. */
+/* A handle is driven by ONE host thread at a time (its own worker threads are internal); different handles and contexts
+ * may be used from different threads concurrently. */
 typedef struct apd_multi apd_multi;
 typedef struct apd_multi_batch apd_multi_batch;
 int apd_multi_create(const int *devices, uint32_t n_devices, apd_multi **multi);
@@ -245,7 +247,8 @@ int apd_multi_align_all(apd_multi *multi, const apd_multi_batch *batch, const ap
 /* ---- device buffers -------------------------------------------------------------------------------------------------
  * For hosts that keep features or the matrix resident between calls (what a Rust binding wraps in a Drop-ing DeviceVec):
  * plain hipMalloc / hipFree / hipMemcpy on the context's device, the copies ordered on the context's stream and
- * complete when the call returns. */
+ * complete when the call returns.  apd_destroy releases the buffers of a context that were never freed (after which they
+ * must not be passed to apd_device_free); freeing a pointer the context did not hand out is APD_ERR_INVALID_ARG. */
 int apd_device_alloc(apd_context *ctx, uint64_t bytes, void **d_ptr);
 int apd_device_free(apd_context *ctx, void *d_ptr);
 int apd_copy_to_device(apd_context *ctx, void *d_dst, const void *src, uint64_t bytes);

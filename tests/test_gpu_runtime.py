@@ -23,7 +23,12 @@ def test_suite_runs_on_the_linked_runtime(apd):
     buf = ctx.alloc(1 << 20)
     buf.fill(0x3C)
     assert set(buf.to_numpy("u1").tolist()) == {0x3C}
+    # a pointer the context did not hand out (or handed out and already released) is refused, not passed to hipFree
+    import ctypes as C
+    assert apd.lib().apd_device_free(ctx.handle, C.c_void_p(buf.ptr + 256)) == apd.APD_ERR_INVALID_ARG
+    keep = ctx.alloc(4096)                                               # never freed by us: apd_destroy releases it
     ctx.close()
+    keep.free()                                                          # after the context: a no-op in the mirror
 
 
 CHILD = r"""
