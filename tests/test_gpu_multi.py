@@ -194,3 +194,35 @@ def test_more_ranks_than_tiles_and_degenerate_batches(apd, oracle):
     empty = m.batch(np.zeros(1, np.uint64), 13, frames=np.zeros((0, 13), np.float32))
     assert m.align_all(empty, cfg).shape == (0, 0)
     m.close()
+
+
+def test_matrix_stays_on_rank_0_for_the_upgma_leg(apd, oracle):
+    """The N-GPU flow of main.rs:187-203: align_all over the handle leaves the matrix in devices[0]'s HBM (apd_multi_result) and
+    apd_clustering runs there on the handle's own context -- nothing crosses PCIe between the two.  Against the oracle pipeline."""
+    from audio_pattern_discovery_amd import sharding
+    n = 64
+    frames, offsets = synth.make_sequences(n, 60, 13, seed=12)
+    cfg = apd.AlignConfig(0.0625, 1.0, 1.0, 1.0)
+    os.environ["APD_MULTI_COLLECTIVE"] = "peer"
+    try:
+        m = sharding.Multi([0, 0, 0, 0])                                # four ranks on the one GPU of a test box
+    finally:
+        del os.environ["APD_MULTI_COLLECTIVE"]
+    for c in m.contexts:
+        c.set_distance_mode("strict")                                   # the oracle's bits, so that the dendrograms must agree exactly
+    mb = m.batch(offsets, 13, frames=frames)
+    m.align_all_async(mb, cfg)
+    m.synchronize()
+    c0 = m.contexts[0]
+    ops = (apd.ClusterOp * n)()
+    roots = np.zeros(n, dtype=np.uint32)
+    n_ops, n_roots, thr = C.c_uint32(0), C.c_uint32(0), C.c_float(0)
+    apd.check(apd.lib().apd_clustering(c0.handle, C.c_void_p(m.result_ptr()), 1, n, 0.3, ops, C.byref(n_ops),
+                                       roots.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n_roots), C.byref(thr)), c0.handle)
+    want_d = oracle.align_all(frames, offsets, 0.0625, workers=8)
+    want_ops, want_roots, want_thr = oracle.clustering(want_d, n, 0.3)
+    assert [(ops[k].merge_i, ops[k].merge_j, ops[k].into) for k in range(n_ops.value)] == [(o["merge_i"], o["merge_j"], o["into"]) for o in want_ops]
+    assert np.array_equal(np.array([ops[k].distance for k in range(n_ops.value)], np.float32).view(np.uint32),
+                          np.array([o["distance"] for o in want_ops], np.float32).view(np.uint32))
+    assert roots[:n_roots.value].tolist() == sorted(want_roots) and thr.value == want_thr
+    m.close()
