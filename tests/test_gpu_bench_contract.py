@@ -55,3 +55,20 @@ def test_bench_secondary_workloads_and_in_process_multi_device():
         assert s["workload"].startswith(name) and s["kernel_ms"] > 0 and 0 < s["roofline_frac"] < 1 and s["parity_ok"] is True
     # the same shape measured twice in one run agrees with itself
     assert abs(d["secondary"]["cfg2"]["kernel_ms"] / d["roofline"]["kernel_ms"] - 1.0) < 0.15
+
+
+def test_bench_gpus_2_in_process_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset -- the driver's N > 1 command -- end to end on a one-GPU box: two ranks of
+    the in-process handle on device 0 (APD_BENCH_DEVICES), slabs gathered by the peer-copy collective (RCCL refuses two ranks on
+    one device).  Checks the line's N > 1 fields; the timing means nothing."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(APD_MULTI_COLLECTIVE="peer", APD_BENCH_DEVICES="0,0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg1", "--steps", "2", "--warmup", "1",
+                          "--cpu-seconds", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["ranks_seen"] == 2
+    assert d["config"]["launch"].startswith("one process driving 2 devices") and d["config"]["torch_imported"] is False
+    assert d["config"]["collective_fallback"] is True and "peer-copy" in d["config"]["collective_error"]
+    assert d["parity_ok"] is True and d["parity_census"]["over_1e-4"] == 0
+    assert "2 ranks" in d["config"]["sharding"] and d["roofline"]["kernel"].startswith("dtw_fused (rank 0 share")
