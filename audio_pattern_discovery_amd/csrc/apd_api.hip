@@ -581,10 +581,25 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const bool pens_ok = (band.ins > 0.0f) && (band.del > 0.0f) && (band.mat > 0.0f) && (band.ins < INFINITY) &&
                          (band.del < INFINITY) && (band.mat < INFINITY);   // the systolic kernel needs pen * INF = INF
-    bool nonfinite = false;                                               // a NaN / infinite feature anywhere: literal kernel only
-    rc = batch_nonfinite(ctx, batch, &nonfinite);
-    if (rc) return rc;
-    const bool fast_ok = pens_ok && batch->frames_bytes != 0 && !nonfinite;
+    // A NaN / infinite feature anywhere in the batch means: literal kernel only (the fast kernels' selects and sentinels assume
+    // finite features).  The repack kernel leaves that verdict in batch->d_flags[0]; it is consumed ON THE DEVICE: the fast
+    // kernels return at once when it is set, and a fallback launch of the generic kernel over the same tiles returns at once when
+    // it is clear (`device_select`).  No host round trip, nothing blocks: the call only enqueues.  The one exception: a band so
+    // wide that the generic kernel cannot hold it in LDS -- then the host reads the flag (a stream synchronisation), as the fast
+    // kernels are the only ones that can run.
+    const bool static_fast = pens_ok && batch->frames_bytes != 0;
+    bool nonfinite = false, device_select = false;
+    if (static_fast) {
+        const uint32_t band_ub = band.use_explicit ? band.explicit_band : host_band_from_pct(band.pct, batch->max_len);
+        const uint32_t w_all = std::max(std::min(band_ub, batch->max_len), batch->max_len - batch->min_len) + 2;   // >= w of every pair
+        device_select = generic_fallback_fits(w_all) && apd_num_tiles(batch->n_seq) * kSlotsPerTile <= 0xFFFFFFFFull &&
+                        !std::getenv("APD_HOST_SELECT");                  // (the env: the old host-side choice, for A/B timing)
+        if (!device_select) {
+            rc = batch_nonfinite(ctx, batch, &nonfinite);
+            if (rc) return rc;
+        }
+    }
+    const bool fast_ok = static_fast && !nonfinite;
     // strict mode: every tile takes the kernels built for unequal penalties -- literal comparison chain on distances computed
     // operation for operation as numerics.rs:114-120 -- which are bit-identical to the CPU arithmetic for ANY penalties
     const bool strict = ctx->distance_mode == 2;
@@ -613,6 +628,7 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
     L.n_seq = batch->n_seq; L.dim = batch->dim; L.dpad = batch->dpad; L.band = band; L.d_slab = d_slab;
     L.variant = ctx->variant;
     L.hybrid = ctx->distance_mode == 1; L.strict = strict; L.tau = ctx->tau;
+    L.d_nonfinite = device_select ? batch->d_flags : nullptr;
     if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     // Classes are independent (disjoint tiles, disjoint slab regions): with more than one, their launches are spread over
     // side streams forked from and joined back into the context's stream, so that a class of a few tiles does not hold the
@@ -639,6 +655,15 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done[k], 0));
         }
     if (rc_launch != APD_OK) return rc_launch;
+    if (device_select) {                                                // the literal kernel behind the fast ones: idle unless the flag is raised
+        uint32_t total = 0, w_max = 0, n_max = 0;
+        for (const apd_batch::TileClass &tc : plan.classes) { total += tc.count; w_max = std::max(w_max, tc.w_max); n_max = std::max(n_max, tc.n_max); }
+        L.d_tiles = plan.d_tiles; L.n_tiles = total; L.w_max = w_max; L.n_max = n_max;
+        if (ctx->drop_tiles) L.n_tiles -= std::min(L.n_tiles, ctx->drop_tiles);
+        bool fits = true;
+        const hipError_t e = launch_generic_fallback(L, ctx->stream, &fits);
+        if (e != hipSuccess || !fits) { ctx->last_error = std::string("launch_generic_fallback: ") + (fits ? hipGetErrorString(e) : "band too wide"); return APD_ERR_HIP; }
+    }
     if (ctx->timing) { HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream)); ctx->timed = true; }
     return APD_OK;
 }

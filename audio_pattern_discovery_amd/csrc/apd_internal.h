@@ -38,6 +38,10 @@ struct AlignLaunch {
     uint32_t dim, dpad;
     BandSpec band;
     float *d_slab;               // [tiles of the rank][2][kTile][kTile]
+    // Device-side choice between the fast kernels and the literal, NaN-faithful one (no host round trip): the word the repack
+    // kernel raises when a frame holds a NaN / infinity.  Fast kernels return at once when it is set; the fallback launch of
+    // the generic kernel (launch_generic_fallback) returns at once when it is clear.  nullptr: no check.
+    const uint32_t *d_nonfinite;
     uint32_t w_max;              // upper bound of w over the pairs of this launch
     uint32_t n_max;              // upper bound of the longer length over the pairs of this launch
     int variant;                 // 0 auto
@@ -58,6 +62,10 @@ constexpr int max_strip_columns(uint32_t d) { return d <= 10 ? 13 : (d <= 13 ? 1
 
 // geom_key = G * 100 + C of the systolic kernel, or 0 for the generic kernel (see pick_geometry_key)
 hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, std::string &err, int *status);
+// The generic kernel over ALL tiles of L as a small persistent grid that does nothing unless *L.d_nonfinite is set.
+// *fits = false (and nothing launched) if the band of L.w_max needs more LDS than a workgroup can have.
+hipError_t launch_generic_fallback(const AlignLaunch &L, hipStream_t stream, bool *fits);
+bool generic_fallback_fits(uint32_t w_max);
 int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen, bool fast_shift);
 // >= 20000: full-matrix kernel, 20000 + (pairs per wavefront) * 100 + CW, for pairs of at most `rows` x `cols` frames (0 if it does not apply)
 int pick_full_key(uint32_t cols, uint32_t rows, uint32_t dim, int variant);   // (>= 10000: wide kernel, 10000 + NW * 100 + C)

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(64) void dtw_full_matrix(const AlignLaunch L)
     constexpr int DN = D + 1;
     constexpr int DP = (DN + 3) & ~3;
     constexpr int PPW = 64 / G;                                   // pairs per wavefront
+    if (L.d_nonfinite != nullptr && *L.d_nonfinite != 0u) return;   // a NaN / infinite feature in the batch: the literal kernel's job
     constexpr int U = 8;                                          // macro-steps per row-ring refill
     constexpr int R = (G == 64) ? 128 : 64;                       // row ring: R > 2U + G - 2
     constexpr int W = G * CW;                                     // columns per pass

@@ -31,11 +31,9 @@
 
 namespace apd {
 
-__global__ __launch_bounds__(64) void dtw_fused_generic(const AlignLaunch L, int c_max)
+__device__ __forceinline__ void generic_pair(const AlignLaunch &L, int c_max, uint32_t wave, float *lds)
 {
-    extern __shared__ float lds[];
     const int lane = threadIdx.x;
-    const uint32_t wave = blockIdx.x;
     const uint32_t tile = wave / kSlotsPerTile, slot = wave % kSlotsPerTile;
     const PairInfo P = decode_pair(L, tile, slot);
     if (!P.valid) return;
@@ -102,6 +100,25 @@ __global__ __launch_bounds__(64) void dtw_fused_generic(const AlignLaunch L, int
     if (lane == ustar / C) {
         const float denom = (float)(n + m);                  // alignments.rs:121
         store_pair(L, tile, P, res1 / denom, res2 / denom);
+    }
+}
+
+// one wavefront per pair slot
+__global__ __launch_bounds__(64) void dtw_fused_generic(const AlignLaunch L, int c_max)
+{
+    extern __shared__ float lds[];
+    generic_pair(L, c_max, blockIdx.x, lds);
+}
+
+// The same as the fallback behind the fast kernels: a small persistent grid over all pair slots of the launch that returns at
+// once unless the batch's non-finite flag is raised (then the fast kernels have returned at once, and this one does the work).
+__global__ __launch_bounds__(64) void dtw_fused_generic_fallback(const AlignLaunch L, int c_max, uint32_t total_waves)
+{
+    extern __shared__ float lds[];
+    if (*L.d_nonfinite == 0u) return;
+    for (uint32_t wave = blockIdx.x; wave < total_waves; wave += gridDim.x) {
+        generic_pair(L, c_max, wave, lds);
+        __syncthreads();                                     // the DP rows in LDS are reused by the next pair
     }
 }
 
@@ -460,6 +477,35 @@ static hipError_t launch_align_chunk(const AlignLaunch &L, int geom_key, hipStre
         const uint64_t waves = (uint64_t)L.n_tiles * kSlotsPerTile;
         hipLaunchKernelGGL(dtw_fused_generic, dim3((uint32_t)waves), dim3(64), lds_bytes, stream, L, c_max);
     }
+    return hipGetLastError();
+}
+
+static size_t generic_lds_bytes(uint32_t w_max, int *c_max_out)
+{
+    int c_max = (int)((2 * (uint64_t)w_max + 1 + 63) / 64);
+    if (c_max < 2) c_max = 2;
+    if (c_max_out) *c_max_out = c_max;
+    return (size_t)c_max * 64 * 2 * sizeof(float);
+}
+
+bool generic_fallback_fits(uint32_t w_max) { return generic_lds_bytes(w_max, nullptr) <= 160 * 1024; }
+
+hipError_t launch_generic_fallback(const AlignLaunch &L, hipStream_t stream, bool *fits)
+{
+    *fits = true;
+    if (L.n_tiles == 0 || L.d_nonfinite == nullptr) return hipSuccess;
+    int c_max = 2;
+    const size_t lds_bytes = generic_lds_bytes(L.w_max, &c_max);
+    if (lds_bytes > 160 * 1024) { *fits = false; return hipSuccess; }
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_fused_generic_fallback),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    const uint64_t waves = (uint64_t)L.n_tiles * kSlotsPerTile;
+    if (waves > 0xFFFFFFFFull) { *fits = false; return hipSuccess; }
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(waves, 256u * 32u);   // 32 single-wave workgroups per CU when it has to work
+    hipLaunchKernelGGL(dtw_fused_generic_fallback, dim3(grid), dim3(64), lds_bytes, stream, L, c_max, (uint32_t)waves);
     return hipGetLastError();
 }
 

@@ -135,6 +135,7 @@ template <int D, int C, int G, bool UNIFORM_PEN, bool HYBRID>
 __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
 {
     static_assert(C >= 2 && (64 % G) == 0, "bad geometry");
+    if (L.d_nonfinite != nullptr && *L.d_nonfinite != 0u) return;   // a NaN / infinite feature in the batch: the literal kernel's job
     constexpr int DN = D + 1;                                  // frame components + squared norm
     constexpr int DP = (DN + 3) & ~3;                          // floats per resident frame
     constexpr int PPW = 64 / G;                                // pairs per wave

@@ -21,6 +21,7 @@ __global__ __launch_bounds__(64 * NW) void dtw_fused_wide(const AlignLaunch L)
 {
     constexpr int G = 64 * NW;
     constexpr int DN = D + 1;
+    if (L.d_nonfinite != nullptr && *L.d_nonfinite != 0u) return;   // a NaN / infinite feature in the batch: the literal kernel's job
     constexpr int DP = (DN + 3) & ~3;
     constexpr int S = C + 1;
     constexpr int U = (S % 2 == 0) ? S : 2 * S;

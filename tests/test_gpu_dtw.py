@@ -654,3 +654,29 @@ def test_sharded_async_through_a_library_owned_communicator(ctx, oracle, apd):
     with pytest.raises(apd.ApdError):
         comm2.count()                                                    # orphaned: refused
     comm2.close()
+
+
+def test_async_alignment_only_enqueues(ctx, apd):
+    """The _async entry points return while the kernels run: the choice between the fast kernels and the literal, NaN-faithful
+    one is made on the device (the repack kernel's flag is read by the kernels, not by the host), so a refill + alignment is
+    two enqueues.  2048 x len~512 (a ~55 ms launch): the calls must take a small fraction of the time the work takes."""
+    import time
+    from audio_pattern_discovery_amd.alignments import Batch
+    n = 2048
+    frames, offsets = synth.make_sequences(n, 512, 13, seed=99)
+    cfg = apd.AlignConfig(0.0625, 1.0, 1.0, 1.0)
+    L = apd.lib()
+    d_frames = ctx.upload(frames)
+    b = Batch(ctx, d_frames.ptr, offsets, 13, on_device=True)
+    out = ctx.alloc(4 * n * n)
+    apd.check(L.apd_align_all_device_async(ctx.handle, b.handle, C.byref(cfg), out.at()), ctx.handle)     # plans, code objects
+    ctx.synchronize()
+    first = out.to_numpy(np.uint32)
+    t0 = time.perf_counter()
+    apd.check(L.apd_batch_refill(ctx.handle, b.handle, d_frames.at(), 1), ctx.handle)
+    apd.check(L.apd_align_all_device_async(ctx.handle, b.handle, C.byref(cfg), out.at()), ctx.handle)
+    t_call = time.perf_counter() - t0
+    ctx.synchronize()
+    t_total = time.perf_counter() - t0
+    assert t_total > 0.03 and t_call < 0.25 * t_total, "calls %.4f s of %.4f s" % (t_call, t_total)
+    assert np.array_equal(out.to_numpy(np.uint32), first)
