@@ -160,12 +160,14 @@ uint64_t apd_num_tiles(uint32_t n_seq);
 uint64_t apd_rank_tiles(uint32_t n_seq, uint32_t rank, uint32_t world);
 uint64_t apd_slab_floats(uint32_t n_seq, uint32_t world);
 /* "_async" for the alignment entry points (this one, apd_align_all_device_async, apd_align_all_sharded_async,
- * apd_multi_align_all_async) means: the kernels, the collective and the unpack are only ENQUEUED when the call returns.  One
- * host-side wait is inside them all the same: the first alignment after apd_batch_create / apd_batch_refill reads the repack
- * kernel's verdict on non-finite frames back (4 bytes D2H and a synchronisation of the context's stream) before it chooses
- * between the fast kernels and the literal, NaN-faithful one; later alignments of the same fill do not wait.  Consequences:
- * not usable inside a stream capture; a pipeline that refills every step is host-serialised with the previous step's
- * kernels (the GPU does not idle for it: the wait ends when the stream is empty, and the launches follow at once). */
+ * apd_multi_align_all_async) means what it says: the kernels, the collective and the unpack are only ENQUEUED when the call
+ * returns, also right after apd_batch_create / apd_batch_refill.  The choice between the fast kernels and the literal,
+ * NaN-faithful one (a batch with a NaN / infinite feature must take the latter) is made ON THE DEVICE: the repack kernel
+ * leaves its verdict in a flag word, the fast kernels return at once when it is raised, and a small persistent launch of the
+ * literal kernel behind them returns at once when it is not.  One exception: a band so wide that the literal kernel cannot
+ * hold it in LDS (2w+1 > 20 480 offsets) -- then the first alignment after a fill reads the flag back on the host (4 bytes,
+ * one synchronisation of the context's stream).  The first call on a new batch / band also builds the tile plan on the host
+ * (a small upload and a stream synchronisation); later calls reuse it. */
 int apd_align_tiles_async(apd_context *ctx, const apd_batch *batch, const apd_align_config *cfg,
                           uint32_t rank, uint32_t world, float *d_slab);
 int apd_unpack_tiles_async(apd_context *ctx, const apd_batch *batch, uint32_t world, const float *d_gathered,
@@ -235,8 +237,7 @@ int apd_multi_batch_refill(apd_multi *multi, apd_multi_batch *batch, const float
 int apd_multi_batch_destroy(apd_multi_batch *batch);
 /* AlignmentWorkers::align_all (alignments.rs:31-67): every device aligns its pair tiles (g = i mod n_devices), ONE grouped
  * ncclAllGather, unpack on devices[0].  d_out: n_seq*n_seq floats in devices[0]'s HBM (NULL: a buffer owned by the handle,
- * see apd_multi_result).  Returns when every device's work is ENQUEUED (the workers wait for their repack kernel's
- * verdict on non-finite frames first: see apd_align_tiles_async); apd_multi_synchronize waits for all devices and
+ * see apd_multi_result).  Returns when every device's work is ENQUEUED; apd_multi_synchronize waits for all devices and
  * reports APD_ERR_INCOMPLETE like apd_synchronize. */
 int apd_multi_align_all_async(apd_multi *multi, const apd_multi_batch *batch, const apd_align_config *cfg, float *d_out);
 int apd_multi_synchronize(apd_multi *multi);
