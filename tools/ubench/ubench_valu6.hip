@@ -23,6 +23,10 @@
 // mode 5: the same with a guard value folded into the integer minimum (k = min3_i32(x, 0, g))
 #define SEL5 "v_xad_u32 %4, %0, %2, -1\n v_min_f32 %0, %0, %2\n v_min3_i32 %4, %4, 0, %1\n v_or_b32 %0, %0, %4\n v_min_f32 %0, %0, %1\n v_add_f32 %0, %0, %3\n" \
              "v_xad_u32 %9, %5, %7, -1\n v_min_f32 %5, %5, %7\n v_min3_i32 %9, %9, 0, %6\n v_or_b32 %5, %5, %9\n v_min_f32 %5, %5, %6\n v_add_f32 %5, %5, %8\n"
+// mode 6: no lane mask, no integer detour: t = min(l, u); e = l - u (0 iff tie); T = fma(|e|, -BIG, m) (m on a tie, hugely
+//         negative otherwise); r = med3(t, m, T) (m on a tie, min(t, m) otherwise); r += d.  %10/%11 hold -BIG in VGPRs.
+#define SEL6 "v_min_f32 %4, %0, %2\n v_sub_f32 %0, %0, %2\n v_fma_f32 %0, |%0|, %10, %1\n v_med3_f32 %4, %4, %1, %0\n v_add_f32 %0, %4, %3\n" \
+             "v_min_f32 %9, %5, %7\n v_sub_f32 %5, %5, %7\n v_fma_f32 %5, |%5|, %10, %6\n v_med3_f32 %9, %9, %6, %5\n v_add_f32 %5, %9, %8\n"
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float *out, int iters)
 {
@@ -36,6 +40,7 @@ __global__ __launch_bounds__(256) void k(float *out, int iters)
         if (MODE == 2) asm volatile(REP8(SEL2) : "+v"(l1), "+v"(m1), "+v"(u1), "+v"(d1), "+v"(t1), "+v"(l2), "+v"(m2), "+v"(u2), "+v"(d2), "+v"(t2), "+s"(tmp) : "s"(ex) : "vcc");
         if (MODE == 4) asm volatile(REP8(SEL4) : "+v"(l1), "+v"(m1), "+v"(u1), "+v"(d1), "+v"(t1), "+v"(l2), "+v"(m2), "+v"(u2), "+v"(d2), "+v"(t2) : "s"(ex) : "vcc");
         if (MODE == 5) asm volatile(REP8(SEL5) : "+v"(l1), "+v"(m1), "+v"(u1), "+v"(d1), "+v"(t1), "+v"(l2), "+v"(m2), "+v"(u2), "+v"(d2), "+v"(t2) : "s"(ex) : "vcc");
+        if (MODE == 6) { float nb = -3.0e38f; asm volatile(REP8(SEL6) : "+v"(l1), "+v"(m1), "+v"(u1), "+v"(d1), "+v"(t1), "+v"(l2), "+v"(m2), "+v"(u2), "+v"(d2), "+v"(t2) : "v"(nb)); }
         if (MODE == 3) asm volatile(REP8(SEL3) : "+v"(l1), "+v"(m1), "+v"(u1), "+v"(d1), "+v"(t1), "+v"(l2), "+v"(m2), "+v"(u2), "+v"(d2), "+v"(t2) : "s"(ex) : "vcc");
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = l1 + m1 + u1 + t1 + l2 + m2 + u2 + t2 + (float)tmp;
@@ -63,6 +68,7 @@ int main()
         printf("  ... mode 1 + s_nop 0                   %.1f\n", run<3>(d, w, 20000));
         printf("  integer form: xad, min, min_i32, or, min, add  %.1f\n", run<4>(d, w, 20000));
         printf("  integer form with a guard (min3_i32)   %.1f\n", run<5>(d, w, 20000));
+        printf("  min + sub + fma(|e|,-BIG,m) + med3 + add  %.1f\n", run<6>(d, w, 20000));
     }
     return 0;
 }
