@@ -30,13 +30,21 @@ for path in find("trace/**/*kernel_trace.csv"):
                 print("dur_ns=%d trace_vgpr_field=%s trace_accum_vgpr_field=%s (compiler figures: tools/check_resources.sh) sgpr=%s lds=%s scratch=%s grid=%s wg=%s %s" % (
                     dur, row.get("VGPR_Count"), row.get("Accum_VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"), row.get("Scratch_Size"),
                     row.get("Grid_Size_X"), row.get("Workgroup_Size_X"), row["Kernel_Name"][:60]))
-print("== PMC (summed over dispatches of the alignment kernel; per-dispatch = /n_dispatch) ==")
+# the dominant alignment kernel of the run (largest total duration): the toy launch bench.py primes the device with, and the
+# idle literal-kernel fallback behind every fast launch, are alignment kernels too and must not dilute the per-dispatch figures
+dominant, dominant_ns = None, -1
+for path in find("trace/**/*kernel_stats.csv"):
+    with open(path) as fp:
+        for row in csv.DictReader(fp):
+            if "apd::dtw_" in row.get("Name", "") and int(row.get("TotalDurationNs") or 0) > dominant_ns:
+                dominant, dominant_ns = row["Name"], int(row["TotalDurationNs"])
+print("== PMC of the dominant alignment kernel: %s (per-dispatch = sum / n_dispatch) ==" % (dominant or "?")[:90])
 for d in find("pmc_*/"):
     sums, n = defaultdict(float), defaultdict(int)
     for path in glob.glob(os.path.join(d, "**/*counter_collection.csv"), recursive=True):
         with open(path) as fp:
             for row in csv.DictReader(fp):
-                if "apd::dtw_" in row.get("Kernel_Name", ""):   # every alignment kernel: dtw_fused_systolic / _wide / _generic, dtw_full_matrix
+                if (row.get("Kernel_Name", "") == dominant) if dominant else ("apd::dtw_" in row.get("Kernel_Name", "")):
                     sums[row["Counter_Name"]] += float(row["Counter_Value"])
                     n[row["Counter_Name"]] += 1
     for k in sorted(sums):
