@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void encode_staged_kernel(const float *__restr
 // the defining sum X_k = sum_s x_s e^(-2 pi i k s / N) otherwise (rustfft plans any length, spectrogram.rs:44-48; the
 // reference's shipped window is 256).  The tables live in LDS, loaded once per workgroup; the four wavefronts of a
 // workgroup never exchange data, so the stages are ordered by the wavefront's own in-order LDS queue, not by barriers.
+// Power-of-two windows: radix-4 passes, and each HALF of a wavefront (32 lanes) transforms a frame of its own.
 struct CepsParams {
     const int16_t *samples;
     const uint64_t *sample_off;   // [n_seq+1] first sample of every recording
@@ -129,6 +130,7 @@ struct CepsParams {
     uint32_t n_seq;
     uint64_t n_frames;
     uint32_t fft, step, L, fstep, K, log2n;   // log2n == 0: N is not a power of two, direct DFT
+    uint32_t frames_per_wave;  // 2: each half of a wavefront transforms a frame of its own (power-of-two windows whose slots fit in LDS); else 1
     const float *hamming;      // [fft]
     const float *triag;        // [L]
     const float2 *twiddle;     // power of two: [fft/2] exp(-2 pi i k / fft); else [fft] exp(-2 pi i t / fft)
@@ -137,6 +139,35 @@ struct CepsParams {
 };
 
 #define APD_WAVE_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+__device__ __forceinline__ float2 cmul(const float2 a, const float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// From the magnitudes of one frame (mag[0 .. N/2) in LDS) to its output row: triangular filterbank with stride L/2, ln(. + 1e-6),
+// DCT-I as a K x K table product, drop 4, subtract the mean of what is left (spectrogram.rs:66-79).  Executed by `gsize`
+// consecutive lanes (a whole wavefront, or one half of it), `gl` = lane within that group; the caller fences before and after.
+__device__ __forceinline__ void finish_frame(const CepsParams &P, const float *t_tri, const float *t_dct, const float *mag, float *conv,
+                                             float *ceps, uint32_t gl, uint32_t gsize, uint64_t frame, bool live)
+{
+    const uint32_t K = P.K;
+    for (uint32_t c = gl; c < K; c += gsize) {                 // convolve (numerics.rs:102-109)
+        const uint32_t p = P.L + c * P.fstep;
+        float dot = 0.0f;
+        for (uint32_t q = 0; q < P.L; ++q) dot = dot + t_tri[q] * mag[p - P.L + q];
+        conv[c] = logf(dot + 1e-6f);                           // :69
+    }
+    APD_WAVE_LDS_FENCE();
+    for (uint32_t k = gl; k < K; k += gsize) {                 // DCT-I (:71-73)
+        float acc = 0.0f;
+        for (uint32_t q = 0; q < K; ++q) acc = acc + t_dct[k * K + q] * conv[q];
+        ceps[k] = acc;
+    }
+    APD_WAVE_LDS_FENCE();
+    float mu = 0.0f;
+    for (uint32_t k = 4; k < K; ++k) mu = mu + ceps[k];        // mean of cepstrum[4..] (:74, numerics.rs:12-18)
+    mu = mu / (float)(K - 4);
+    if (live)
+        for (uint32_t k = 4 + gl; k < K; k += gsize) P.out[frame * (K - 4) + (k - 4)] = ceps[k] - mu;   // :75-79
+}
 
 __global__ __launch_bounds__(256) void cepstrum_kernel(const CepsParams P)
 {
@@ -151,47 +182,78 @@ __global__ __launch_bounds__(256) void cepstrum_kernel(const CepsParams P)
     for (uint32_t e = threadIdx.x; e < K * K; e += blockDim.x) t_dct[e] = P.dct[e];
     for (uint32_t e = threadIdx.x; e < n_tw; e += blockDim.x) t_tw[e] = P.twiddle[e];
     __syncthreads();
-    // per wavefront: two complex buffers of N/2 (ping-pong; the direct form uses the first as N real samples), mag[half], conv[K], ceps[K]
-    float *base = reinterpret_cast<float *>(t_tw + n_tw) + (size_t)wave * ((2 * N + half + 2 * K + 1u) & ~1u);
-    float2 *bufa = reinterpret_cast<float2 *>(base), *bufb = bufa + half;
-    float *mag = base + 2 * N, *conv = mag + half, *ceps = conv + K;
+    // per frame slot: two complex buffers of N/2 (ping-pong; the direct form uses the first as N real samples), mag[half], conv[K], ceps[K].
+    // Power-of-two windows: TWO slots per wavefront -- each half of the wave (32 lanes) transforms a frame of its own; else one.
+    const uint32_t slot_floats = (2 * N + half + 2 * K + 1u) & ~1u, slots = P.frames_per_wave;
+    float *wave_base = reinterpret_cast<float *>(t_tw + n_tw) + (size_t)wave * slots * slot_floats;
     // A wavefront takes a CONTIGUOUS run of frames: consecutive frames of a recording overlap (dft_step < dft_win: their samples
     // come from L2 the second time) and the recording index only ever steps forward (one binary search per run, not per frame).
     const uint64_t n_waves = (uint64_t)gridDim.x * 4u, per_wave = (P.n_frames + n_waves - 1) / n_waves;
     const uint64_t f_begin = ((uint64_t)blockIdx.x * 4u + wave) * per_wave, f_end = min(f_begin + per_wave, P.n_frames);
+    const uint32_t gsize = 64u / slots, gl = (uint32_t)lane % gsize, fs = (uint32_t)lane / gsize;   // lane group = frame slot
+    float *base = wave_base + (size_t)fs * slot_floats;
+    float2 *bufa = reinterpret_cast<float2 *>(base), *bufb = bufa + half;
+    float *mag = base + 2 * N, *conv = mag + half, *ceps = conv + K;
+    // recording holding this group's first frame: largest s with frame_off[s] <= frame
     uint32_t lo = 0;
-    if (f_begin < f_end) {
-        uint32_t hi = P.n_seq;                                     // recording holding the first frame: largest s with frame_off[s] <= frame
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (P.frame_off[mid] <= f_begin) lo = mid; else hi = mid; }
+    const uint64_t f_first = f_begin + fs;
+    if (f_first < f_end) {
+        uint32_t hi = P.n_seq;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (P.frame_off[mid] <= f_first) lo = mid; else hi = mid; }
     }
-    uint64_t next_off = f_begin < f_end ? P.frame_off[lo + 1] : 0, this_off = f_begin < f_end ? P.frame_off[lo] : 0, samp0 = f_begin < f_end ? P.sample_off[lo] : 0;
-    for (uint64_t frame = f_begin; frame < f_end; ++frame) {
-        while (frame >= next_off) { ++lo; this_off = next_off; next_off = P.frame_off[lo + 1]; samp0 = P.sample_off[lo]; }   // recordings without frames are skipped
-        const uint64_t start = samp0 + (frame - this_off) * P.step;   // i - fft_size, i = fft + t * step (:51-53)
+    uint64_t next_off = f_first < f_end ? P.frame_off[lo + 1] : 0, this_off = f_first < f_end ? P.frame_off[lo] : 0, samp0 = f_first < f_end ? P.sample_off[lo] : 0;
+    for (uint64_t f0 = f_begin; f0 < f_end; f0 += slots) {
+        const uint64_t frame = f0 + fs;
+        const bool live = frame < f_end;                           // an odd run leaves the second half of the wave without a frame
+        if (live)
+            while (frame >= next_off) { ++lo; this_off = next_off; next_off = P.frame_off[lo + 1]; samp0 = P.sample_off[lo]; }   // recordings without frames are skipped
+        const uint64_t start = live ? samp0 + (frame - this_off) * P.step : 0;   // i - fft_size, i = fft + t * step (:51-53)
         if (P.log2n) {
             // real input: the N samples are packed as M = N/2 complex values z[s] = x[2s] + i x[2s+1], one M-point FFT is
             // run (half the butterflies and half the LDS traffic of an N-point transform of zero-imaginary data), and the
-            // N-point spectrum of the real signal follows from Z[k] and conj(Z[M-k]).
-            const uint32_t M = half, hm = M / 2;
-            for (uint32_t s = lane; s < M; s += 64)
-                bufa[s] = make_float2((float)P.samples[start + 2 * s] * t_ham[2 * s], (float)P.samples[start + 2 * s + 1] * t_ham[2 * s + 1]);   // :55-59
+            // N-point spectrum of the real signal follows from Z[k] and conj(Z[M-k]).  The M-point transform is an autosort
+            // (Stockham) FFT in radix-4 passes with one radix-2 pass at the end when log2(M) is odd: M = 128 takes 4 LDS round
+            // trips instead of 7, and a radix-4 pass of 32 butterflies is exactly one half-wave.
+            const uint32_t M = half, m = P.log2n - 1u, n4 = m / 2u;
+            for (uint32_t s = gl; s < M; s += gsize)
+                bufa[s] = live ? make_float2((float)P.samples[start + 2 * s] * t_ham[2 * s], (float)P.samples[start + 2 * s + 1] * t_ham[2 * s + 1])
+                               : make_float2(0.0f, 0.0f);           // :55-59
             APD_WAVE_LDS_FENCE();
             float2 *src = bufa, *dst = bufb;
-            for (uint32_t st = 0; st + 1 < P.log2n; ++st) {
-                const uint32_t Ns = 1u << st;
-                for (uint32_t j = lane; j < hm; j += 64) {
-                    const uint32_t k = j & (Ns - 1);
-                    const float2 w = t_tw[k * (half / Ns)];        // exp(-2 pi i k / (2 Ns))
-                    const float2 p = src[j], q0 = src[j + hm];
-                    const float2 q = make_float2(q0.x * w.x - q0.y * w.y, q0.x * w.y + q0.y * w.x);
+            uint32_t Ns = 1;
+            for (uint32_t st = 0; st < n4; ++st) {
+                const uint32_t q = M / 4u;
+                for (uint32_t j = gl; j < q; j += gsize) {
+                    const uint32_t k = j & (Ns - 1u);
+                    const float2 w1 = t_tw[k * (half / 2u / Ns)];   // exp(-2 pi i k / (4 Ns))
+                    const float2 w2 = t_tw[k * (half / Ns)];        // its square
+                    const float2 w3 = cmul(w1, w2);
+                    const float2 v0 = src[j], v1 = cmul(src[j + q], w1), v2 = cmul(src[j + 2u * q], w2), v3 = cmul(src[j + 3u * q], w3);
+                    const float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y), a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
+                    const float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y), a3 = make_float2(v1.y - v3.y, v3.x - v1.x);   // -i (v1 - v3)
+                    const uint32_t idx = ((j - k) << 2) + k;
+                    dst[idx] = make_float2(a0.x + a2.x, a0.y + a2.y);
+                    dst[idx + Ns] = make_float2(a1.x + a3.x, a1.y + a3.y);
+                    dst[idx + 2u * Ns] = make_float2(a0.x - a2.x, a0.y - a2.y);
+                    dst[idx + 3u * Ns] = make_float2(a1.x - a3.x, a1.y - a3.y);
+                }
+                APD_WAVE_LDS_FENCE();
+                float2 *tmp = src; src = dst; dst = tmp;
+                Ns <<= 2;
+            }
+            if (m & 1u) {                                           // the last, radix-2 pass: Ns = M / 2
+                const uint32_t hm = M / 2u;
+                for (uint32_t j = gl; j < hm; j += gsize) {
+                    const uint32_t k = j & (Ns - 1u);
+                    const float2 p = src[j], qv = cmul(src[j + hm], t_tw[k * (half / Ns)]);   // exp(-2 pi i k / (2 Ns))
                     const uint32_t idx = ((j - k) << 1) + k;
-                    dst[idx] = make_float2(p.x + q.x, p.y + q.y);
-                    dst[idx + Ns] = make_float2(p.x - q.x, p.y - q.y);
+                    dst[idx] = make_float2(p.x + qv.x, p.y + qv.y);
+                    dst[idx + Ns] = make_float2(p.x - qv.x, p.y - qv.y);
                 }
                 APD_WAVE_LDS_FENCE();
                 float2 *tmp = src; src = dst; dst = tmp;
             }
-            for (uint32_t k = lane; k < M; k += 64) {
+            for (uint32_t k = gl; k < M; k += gsize) {
                 const float2 zk = src[k], zm = src[(M - k) & (M - 1)], w = t_tw[k];   // w = exp(-2 pi i k / N)
                 const float ax = 0.5f * (zk.x + zm.x), ay = 0.5f * (zk.y - zm.y);     // (Z[k] + conj Z[M-k]) / 2
                 const float bx = zk.x - zm.x, by = zk.y + zm.y;                       //  Z[k] - conj Z[M-k]
@@ -217,24 +279,8 @@ __global__ __launch_bounds__(256) void cepstrum_kernel(const CepsParams P)
             }
         }
         APD_WAVE_LDS_FENCE();
-        for (uint32_t c = lane; c < K; c += 64) {                  // convolve (numerics.rs:102-109)
-            const uint32_t p = P.L + c * P.fstep;
-            float dot = 0.0f;
-            for (uint32_t q = 0; q < P.L; ++q) dot = dot + t_tri[q] * mag[p - P.L + q];
-            conv[c] = logf(dot + 1e-6f);                           // :69
-        }
-        APD_WAVE_LDS_FENCE();
-        for (uint32_t k = lane; k < K; k += 64) {                  // DCT-I (:71-73)
-            float acc = 0.0f;
-            for (uint32_t q = 0; q < K; ++q) acc = acc + t_dct[k * K + q] * conv[q];
-            ceps[k] = acc;
-        }
-        APD_WAVE_LDS_FENCE();
-        float mu = 0.0f;
-        for (uint32_t k = 4; k < K; ++k) mu = mu + ceps[k];        // mean of cepstrum[4..] (:74, numerics.rs:12-18)
-        mu = mu / (float)(K - 4);
-        for (uint32_t k = 4 + lane; k < K; k += 64) P.out[frame * (K - 4) + (k - 4)] = ceps[k] - mu;   // :75-79
-        APD_WAVE_LDS_FENCE();                                      // the buffers are reused by this wavefront's next frame
+        finish_frame(P, t_tri, t_dct, mag, conv, ceps, gl, gsize, frame, live);
+        APD_WAVE_LDS_FENCE();                                      // the buffers are reused by this lane group's next frame
     }
 }
 
@@ -423,13 +469,16 @@ static int cepstrum_impl(apd_context *ctx, const int16_t *samples, const uint64_
     P.twiddle = reinterpret_cast<const float2 *>(d_tab + tw_off);
     P.out = on_device ? out : reinterpret_cast<float *>(pool + out_off);
     const size_t table_floats = tw_off + 2 * (size_t)n_tw;                               // the kernel lays its LDS out the same way
-    const size_t lds_bytes = (table_floats + 4 * ((2 * (size_t)fft_size + half + 2 * K + 1) & ~(size_t)1)) * sizeof(float);
+    const size_t slot_floats = (2 * (size_t)fft_size + half + 2 * K + 1) & ~(size_t)1;
+    // two frames per wavefront for power-of-two windows, if eight slots fit beside the tables (windows up to 1024 do)
+    P.frames_per_wave = (log2n && (table_floats + 8 * slot_floats) * sizeof(float) <= 96 * 1024) ? 2u : 1u;
+    const size_t lds_bytes = (table_floats + 4 * P.frames_per_wave * slot_floats) * sizeof(float);
     if (lds_bytes > 160 * 1024) rc = APD_ERR_UNSUPPORTED;
     if (rc == APD_OK && lds_bytes > 64 * 1024)
         guard(hipFuncSetAttribute(reinterpret_cast<const void *>(cepstrum_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     if (rc == APD_OK) {
         // wavefronts loop over frames: enough workgroups to fill the GPU several times over, tables loaded once per workgroup
-        const unsigned blocks = (unsigned)std::min<uint64_t>((T + 3) / 4, 256 * 16);
+        const unsigned blocks = (unsigned)std::min<uint64_t>((T + 4 * P.frames_per_wave - 1) / (4 * P.frames_per_wave), 256 * 16);
         hipLaunchKernelGGL(cepstrum_kernel, dim3(blocks), dim3(256), lds_bytes, ctx->stream, P);
         guard(hipGetLastError());
     }
