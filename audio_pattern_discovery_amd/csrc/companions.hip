@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void encode_staged_kernel(const float *__restr
 // -------------------------------------------------------------------------------------- cepstrum
 // One wavefront per frame, wavefronts loop over frames.  Hamming window, DFT of the N real samples, magnitudes of the
 // first N/2 bins, triangular filterbank with stride L/2, ln(. + 1e-6), DCT-I as a K x K table product, drop 4, subtract
-// the mean of what is left (spectrogram.rs:51-79).  The DFT is a radix-2 Stockham FFT in LDS when N is a power of two and
+// the mean of what is left (spectrogram.rs:51-79).  The DFT is an autosort (Stockham) FFT in LDS, radix-4 passes, when N is a power of two and
 // the defining sum X_k = sum_s x_s e^(-2 pi i k s / N) otherwise (rustfft plans any length, spectrogram.rs:44-48; the
 // reference's shipped window is 256).  The tables live in LDS, loaded once per workgroup; the four wavefronts of a
 // workgroup never exchange data, so the stages are ordered by the wavefront's own in-order LDS queue, not by barriers.
