@@ -152,17 +152,20 @@ __device__ __forceinline__ void finish_frame(const CepsParams &P, const float *t
     for (uint32_t c = gl; c < K; c += gsize) {                 // convolve (numerics.rs:102-109)
         const uint32_t p = P.L + c * P.fstep;
         float dot = 0.0f;
+#pragma unroll 4
         for (uint32_t q = 0; q < P.L; ++q) dot = dot + t_tri[q] * mag[p - P.L + q];
         conv[c] = logf(dot + 1e-6f);                           // :69
     }
     APD_WAVE_LDS_FENCE();
     for (uint32_t k = gl; k < K; k += gsize) {                 // DCT-I (:71-73)
         float acc = 0.0f;
+#pragma unroll 4
         for (uint32_t q = 0; q < K; ++q) acc = acc + t_dct[k * K + q] * conv[q];
         ceps[k] = acc;
     }
     APD_WAVE_LDS_FENCE();
     float mu = 0.0f;
+#pragma unroll 4
     for (uint32_t k = 4; k < K; ++k) mu = mu + ceps[k];        // mean of cepstrum[4..] (:74, numerics.rs:12-18)
     mu = mu / (float)(K - 4);
     if (live)
