@@ -94,3 +94,32 @@ def test_length_order_is_longest_first_and_stable():
     order = sharding.length_order(offsets)
     assert order.tolist() == [1, 4, 5, 0, 2, 6, 3]            # equal lengths keep ascending index
     assert sharding.length_order(np.zeros(1, dtype=np.uint64)).tolist() == []
+
+
+def test_file_rendezvous_control_plane(tmp_path):
+    """bench.py's process-per-GPU mode hands the 128-byte communicator id and the per-rank status lines around through a
+    directory in /tmp (no torch, no sockets).  Three rank processes of one parent: everyone reads rank 0's blob, everyone sees
+    everyone's status in rank order, the directory is gone afterwards."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys; sys.path.insert(0, %r); import bench\n"
+        "rank, world = int(sys.argv[1]), 3\n"
+        "r = bench.FileRendezvous(rank, world)\n"
+        "if rank == 0: r.put('id', bytes(range(128)))\n"
+        "blob = r.get('id', 60)\n"
+        "st = r.gather_status('' if rank != 1 else 'rank 1: boom', timeout=60)\n"
+        "print(len(blob), blob[5], st, r.dir)\n"
+        "r.finish()\n" % root)
+    env = dict(os.environ, MASTER_PORT="45991", APD_RDZV_DIR=str(tmp_path))
+    env.pop("TORCHELASTIC_RUN_ID", None)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, text=True, env=env) for r in range(3)]
+    outs = [p.communicate(timeout=120)[0].strip() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    dirs = set()
+    for o in outs:
+        n, b5, st, d = o.split(" ", 3)[0], o.split(" ", 3)[1], o[o.index("["):o.rindex("]") + 1], o.rsplit(" ", 1)[1]
+        assert (n, b5) == ("128", "5") and st == "['', 'rank 1: boom', '']"
+        dirs.add(d)
+    assert len(dirs) == 1 and not os.path.exists(dirs.pop())            # one directory for the three ranks, removed by rank 0
