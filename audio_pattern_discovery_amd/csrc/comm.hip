@@ -278,7 +278,7 @@ int multi_fail(apd_multi *m, int rc, const std::string &what)
 
 }  // namespace
 
-extern "C" int apd_multi_create(const int *devices, uint32_t n_devices, apd_multi **out)
+static int apd_multi_create_impl(const int *devices, uint32_t n_devices, apd_multi **out)
 {
     if (!devices || n_devices == 0 || !out) return APD_ERR_INVALID_ARG;
     *out = nullptr;
@@ -362,7 +362,7 @@ extern "C" const char *apd_multi_last_error(const apd_multi *m) { return m ? m->
 extern "C" apd_context *apd_multi_context(apd_multi *m, uint32_t i) { return (m && i < nd(m)) ? m->ctx[i] : nullptr; }
 extern "C" const float *apd_multi_result(const apd_multi *m) { return m ? m->last_result : nullptr; }
 
-extern "C" int apd_multi_batch_create(apd_multi *m, const float *frames, const float *const *d_frames, const uint64_t *offsets,
+static int apd_multi_batch_create_impl(apd_multi *m, const float *frames, const float *const *d_frames, const uint64_t *offsets,
                                       uint32_t n_seq, uint32_t dim, apd_multi_batch **out)
 {
     if (!m || !offsets || !out) return APD_ERR_INVALID_ARG;
@@ -385,7 +385,7 @@ extern "C" int apd_multi_batch_create(apd_multi *m, const float *frames, const f
     return APD_OK;
 }
 
-extern "C" int apd_multi_batch_refill(apd_multi *m, apd_multi_batch *mb, const float *frames, const float *const *d_frames)
+static int apd_multi_batch_refill_impl(apd_multi *m, apd_multi_batch *mb, const float *frames, const float *const *d_frames)
 {
     if (!m || !mb || mb->multi != m) return APD_ERR_INVALID_ARG;
     if (!frames && !d_frames && mb->n_seq) return APD_ERR_INVALID_ARG;
@@ -405,7 +405,7 @@ extern "C" int apd_multi_batch_destroy(apd_multi_batch *mb)
     return APD_OK;
 }
 
-extern "C" int apd_multi_align_all_async(apd_multi *m, const apd_multi_batch *mb, const apd_align_config *cfg, float *d_out)
+static int apd_multi_align_all_async_impl(apd_multi *m, const apd_multi_batch *mb, const apd_align_config *cfg, float *d_out)
 {
     if (!m || !mb || !cfg || mb->multi != m) return APD_ERR_INVALID_ARG;
     const uint32_t n = nd(m), n_seq = mb->n_seq;
@@ -469,7 +469,7 @@ extern "C" int apd_multi_align_all_async(apd_multi *m, const apd_multi_batch *mb
     return APD_OK;
 }
 
-extern "C" int apd_multi_synchronize(apd_multi *m)
+static int apd_multi_synchronize_impl(apd_multi *m)
 {
     if (!m) return APD_ERR_INVALID_ARG;
     std::vector<int> rc(nd(m), APD_OK);
@@ -477,7 +477,7 @@ extern "C" int apd_multi_synchronize(apd_multi *m)
     return merge_status(m, rc);
 }
 
-extern "C" int apd_multi_align_all(apd_multi *m, const apd_multi_batch *mb, const apd_align_config *cfg, float *out)
+static int apd_multi_align_all_impl(apd_multi *m, const apd_multi_batch *mb, const apd_align_config *cfg, float *out)
 {
     if (!m || !mb || !cfg || mb->multi != m || (!out && mb->n_seq)) return APD_ERR_INVALID_ARG;
     if (mb->n_seq == 0) return APD_OK;
@@ -492,7 +492,7 @@ extern "C" int apd_multi_align_all(apd_multi *m, const apd_multi_batch *mb, cons
 }
 
 // One-shot form: everything above made and torn down inside one call (kept for callers that align once).
-extern "C" int apd_align_all_multi(const int *devices, uint32_t n_devices, const float *frames, const uint64_t *offsets, uint32_t n_seq,
+static int apd_align_all_multi_impl(const int *devices, uint32_t n_devices, const float *frames, const uint64_t *offsets, uint32_t n_seq,
                                    uint32_t dim, const apd_align_config *cfg, float *out, uint32_t *ranks_seen)
 {
     if (!devices || n_devices == 0 || !offsets || !cfg || (n_seq && !out)) return APD_ERR_INVALID_ARG;
@@ -507,6 +507,21 @@ extern "C" int apd_align_all_multi(const int *devices, uint32_t n_devices, const
     apd_multi_destroy(m);
     return rc;
 }
+
+
+// ---- the C boundary of the entry points above: nothing unwinds across it (std::bad_alloc, std::system_error of a thread
+// that cannot be started, ...) ------------------------------------------------------------------------------------------
+#define APD_GUARDED(call)                                              \
+    try { return call; }                                              \
+    catch (const std::bad_alloc &) { return APD_ERR_OOM; }            \
+    catch (...) { return APD_ERR_HIP; }
+extern "C" int apd_multi_create(const int *devices, uint32_t n_devices, apd_multi **out) { APD_GUARDED(apd_multi_create_impl(devices, n_devices, out)) }
+extern "C" int apd_multi_batch_create(apd_multi *m, const float *frames, const float *const *d_frames, const uint64_t *offsets, uint32_t n_seq, uint32_t dim, apd_multi_batch **out) { APD_GUARDED(apd_multi_batch_create_impl(m, frames, d_frames, offsets, n_seq, dim, out)) }
+extern "C" int apd_multi_batch_refill(apd_multi *m, apd_multi_batch *mb, const float *frames, const float *const *d_frames) { APD_GUARDED(apd_multi_batch_refill_impl(m, mb, frames, d_frames)) }
+extern "C" int apd_multi_align_all_async(apd_multi *m, const apd_multi_batch *mb, const apd_align_config *cfg, float *d_out) { APD_GUARDED(apd_multi_align_all_async_impl(m, mb, cfg, d_out)) }
+extern "C" int apd_multi_synchronize(apd_multi *m) { APD_GUARDED(apd_multi_synchronize_impl(m)) }
+extern "C" int apd_multi_align_all(apd_multi *m, const apd_multi_batch *mb, const apd_align_config *cfg, float *out) { APD_GUARDED(apd_multi_align_all_impl(m, mb, cfg, out)) }
+extern "C" int apd_align_all_multi(const int *devices, uint32_t n_devices, const float *frames, const uint64_t *offsets, uint32_t n_seq, uint32_t dim, const apd_align_config *cfg, float *out, uint32_t *ranks_seen) { APD_GUARDED(apd_align_all_multi_impl(devices, n_devices, frames, offsets, n_seq, dim, cfg, out, ranks_seen)) }
 
 // ------------------------------------------------------------------------------------------------------ runtime identity
 extern "C" uint64_t apd_runtime_info(char *out, uint64_t capacity)
