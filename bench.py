@@ -652,7 +652,7 @@ def main():
                                      line["parity_census"]["nonfinite_pattern_equal"] and line["parity_census"]["zero_pattern_equal"])
             if line["parity_census"]["over_1e-4"]:
                 line["parity_note"] = ("%d of %d entries beyond 1e-4 in the default distance form: the coincidental-tie deviation (DESIGN.md section 6, "
-                                       "3-7 entries in 1e8 on the BASELINE shapes); --distance strict computes the reference's bits at 2.06x the time"
+                                       "1-6 entries in 1e8 on the BASELINE shapes); --distance strict computes the reference's bits at 2.06x the time"
                                        % (line["parity_census"]["over_1e-4"], line["parity_census"]["entries"]))
         if inp["frames"] is not None and inp["enc_w"] is None and world == 1:
             # the host-buffer entry of the boundary (AlignmentWorkers::new + align_all on host Vec<f32>s): H2D of the frames,

@@ -108,7 +108,7 @@ int apd_set_variant(apd_context *ctx, int variant);
  * MATCH even when MATCH is larger; when such a tie arises by coincidence of two rounded f32 sums (real-valued features),
  * mode 1 -- whose distances differ in the last bit -- does not see a tie and keeps the smaller predecessor, and that entry can
  * differ by a few 1e-4 relative.  Counted over every entry of the BASELINE shapes (tests/test_gpu_census.py): none on cfg 2,
- * cfg 3 and cfg 5's shape, one pair of 8.4 million on cfg 4; over 16 corpora per shape 3-7 entries in 1e8, worst 5e-4
+ * cfg 3 and cfg 5's shape, one pair of 8.4 million on cfg 4; over 60 corpora per shape 1-6 entries in 1e8, worst seen 2.2e-3
  * (tools/census_sweep.py).  Ties that are structural (identical frames, integer features,
  * +INF) are reproduced in every mode. */
 int apd_set_distance_mode(apd_context *ctx, int mode, float tau);
