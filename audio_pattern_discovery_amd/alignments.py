@@ -153,7 +153,14 @@ class AlignmentWorkers:
     `result` (n*n, row-major, diagonal 0.0) is filled.  `alignment_workers` is accepted and ignored:
     the GPU grid replaces the OS threads of :35-41."""
 
-    def __init__(self, data, ctx=None):     # AlignmentWorkers::new, :17-26
+    def __init__(self, data, ctx=None, devices=None):     # AlignmentWorkers::new, :17-26
+        """`devices`: HIP device ordinals -- the workers of :33-41 become these GPUs, driven through the library's persistent
+        multi-device handle (made here once; every align_all then pays kernels + one all-gather + unpack)."""
+        self._multi = None
+        if devices is not None:
+            from . import sharding
+            self._multi = sharding.Multi(devices)
+            ctx = self._multi.contexts[0]
         self.ctx = ctx or _lib.default_context()
         self.data = list(data)
         n = len(self.data)
@@ -167,17 +174,30 @@ class AlignmentWorkers:
         offsets[1:] = np.cumsum(lens)
         frames = (np.concatenate([s.frames for s in self.data], axis=0) if n
                   else np.zeros((0, self._dim), np.float32))
-        self._batch = Batch(self.ctx, frames, offsets, self._dim)
+        self._batch = (self._multi.batch(offsets, self._dim, frames=frames) if self._multi is not None
+                       else Batch(self.ctx, frames, offsets, self._dim))
 
     @staticmethod
-    def new(data, ctx=None):
-        return AlignmentWorkers(data, ctx)
+    def new(data, ctx=None, devices=None):
+        return AlignmentWorkers(data, ctx, devices)
 
     def align_all(self, params):            # :31-67, params: Discovery
         cfg = params.align_config()
+        if self._multi is not None:
+            self.result[:] = self._multi.align_all(self._batch, cfg).ravel()
+            return self.result
         _lib.check(_lib.lib().apd_align_all(self.ctx.handle, self._batch.handle, C.byref(cfg),
                                             self.result.ctypes.data_as(C.POINTER(C.c_float))), self.ctx.handle)
         return self.result
+
+    def close(self):
+        """Releases the GPU side (the reference's Drop of the Arcs)."""
+        if self._batch is not None:
+            self._batch.close()
+            self._batch = None
+        if self._multi is not None:
+            self._multi.close()
+            self._multi = None
 
 
 def align_work(offsets, dim, cfg, rank=0, world=1):

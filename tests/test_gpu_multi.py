@@ -226,3 +226,20 @@ def test_matrix_stays_on_rank_0_for_the_upgma_leg(apd, oracle):
                           np.array([o["distance"] for o in want_ops], np.float32).view(np.uint32))
     assert roots[:n_roots.value].tolist() == sorted(want_roots) and thr.value == want_thr
     m.close()
+
+
+def test_alignment_workers_mirror_over_devices(apd, oracle):
+    """The Python mirror of AlignmentWorkers with `devices`: new() makes the handle and the resident corpus once, align_all()
+    is called twice (main.rs:187-195 in a loop) -- same bits as the single-GPU mirror."""
+    from audio_pattern_discovery_amd.alignments import AlignmentWorkers, NDSequence
+    from audio_pattern_discovery_amd.discovery import Discovery
+    frames, offsets = synth.make_sequences(48, 70, 13, seed=14)
+    seqs = [NDSequence(s) for s in synth.split(frames, offsets)]
+    cfg = Discovery(warping_band_percentage=0.0625)
+    single = AlignmentWorkers.new(seqs, apd.Context(0)).align_all(cfg).copy()
+    w = AlignmentWorkers.new(seqs, devices=[0])
+    first = w.align_all(cfg).copy()
+    second = w.align_all(cfg).copy()
+    w.close()
+    assert np.array_equal(first.view(np.uint32), single.view(np.uint32)) and np.array_equal(second.view(np.uint32), single.view(np.uint32))
+    assert_parity(first.reshape(48, 48), oracle.align_all(frames, offsets, 0.0625, workers=8))
