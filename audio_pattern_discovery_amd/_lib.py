@@ -86,6 +86,7 @@ SYMBOLS = [
     ("apd_set_variant", C.c_int, [_vp, C.c_int]),
     ("apd_set_distance_mode", C.c_int, [_vp, C.c_int, C.c_float]),
     ("apd_selftest", C.c_int, [_vp]),
+    ("apd_selftest_sqrt", C.c_int, [_vp, C.c_uint32, C.c_uint64, _u64p, _u32p, _u64p]),
     ("apd_set_fault_injection", C.c_int, [_vp, C.c_uint32]),
     ("apd_batch_refill", C.c_int, [_vp, _vp, _vp, C.c_int]),
     ("apd_batch_nonfinite", C.c_int, [_vp, _vp, C.POINTER(C.c_int)]),
@@ -248,6 +249,13 @@ class Context:
 
     def selftest(self):
         check(lib().apd_selftest(self.handle), self.handle)
+
+    def selftest_sqrt(self, first_bits, count):
+        """TEST HOOK: strict mode's square root against the correctly rounded one over `count` consecutive f32 bit patterns.
+        Returns (mismatches, first mismatching pattern, [bare v_sqrt_f32 ulp-offset counts for <=-2, -1, 0, +1, >=+2])."""
+        bad, first, hist = C.c_uint64(0), C.c_uint32(0), (C.c_uint64 * 5)()
+        check(lib().apd_selftest_sqrt(self.handle, first_bits, count, C.byref(bad), C.byref(first), hist), self.handle)
+        return bad.value, first.value, list(hist)
 
     def set_fault_injection(self, drop_tiles):
         """TEST HOOK: the next alignment launches skip the last `drop_tiles` tiles of every kernel class."""

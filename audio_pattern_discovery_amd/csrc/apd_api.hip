@@ -239,6 +239,25 @@ extern "C" int apd_selftest(apd_context *ctx)
     return APD_OK;
 }
 
+extern "C" int apd_selftest_sqrt(apd_context *ctx, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint32_t *first_mismatch,
+                                 uint64_t *raw_ulp_hist)
+{
+    if (!ctx || !mismatches || count > (1ull << 32)) return APD_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_ws(ctx, &ctx->ws_misc, &ctx->ws_misc_bytes, 256);
+    if (rc) return rc;
+    unsigned long long h[7] = {0, ~0ull, 0, 0, 0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_misc, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                       // h is a stack buffer
+    if (count) HIP_TRY(ctx, launch_sqrt_sweep(first_bits, count, (unsigned long long *)ctx->ws_misc, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->ws_misc, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *mismatches = h[0];
+    if (first_mismatch) *first_mismatch = h[0] ? (uint32_t)(h[1] - 1ull) : 0u;
+    if (raw_ulp_hist) for (int k = 0; k < 5; ++k) raw_ulp_hist[k] = h[2 + k];
+    return APD_OK;
+}
+
 // --------------------------------------------------------------------- Discovery::alignment_params
 
 extern "C" int apd_discovery_alignment_params(const apd_align_config *cfg, uint64_t n_size, apd_alignment_params *out)

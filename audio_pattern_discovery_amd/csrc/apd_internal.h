@@ -82,6 +82,10 @@ hipError_t launch_pad(const float *d_src, float *d_dst, const uint32_t *d_seq_of
 hipError_t launch_unpack(const float *d_gathered, float *d_out, const uint32_t *d_order, uint32_t n_seq, uint32_t world,
                          uint64_t slab_floats, const uint32_t *d_flags, uint32_t *d_status, hipStream_t stream);
 hipError_t launch_selftest(int *d_result, hipStream_t stream);
+hipError_t launch_sqrt_sweep(uint32_t first, uint64_t count, unsigned long long *d_out, hipStream_t stream);
+// Features of magnitude >= 2^60 (or NaN / infinite) raise the batch's flag: below it every squared distance and every frame
+// norm is finite (26 * (2 * 2^60)^2 < 2^127), which the fast kernels' square roots and norm expansion rely on.
+constexpr float kFeatureBound = 0x1p60f;
 
 // comm.hip: called by apd_destroy for every communicator still alive on the context
 void orphan_comm(apd_comm *comm);

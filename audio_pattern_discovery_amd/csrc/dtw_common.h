@@ -76,6 +76,27 @@ __device__ __forceinline__ float group_from_upper_wrap(float v, float fill, int 
     return group_from_upper<G>(v, fill, gl);
 }
 
+// Correctly rounded f32 square root (the bits of Rust's f32::sqrt, numerics.rs:119) for 2^-96 <= x < +INF, in 7 vector ops:
+// s = v_sqrt_f32(x) is within one ulp; with s- / s+ its neighbours, the fused residuals x - s s- and x - s s+ are computed
+// without rounding error that could change their sign (LLVM's own lowering rests on the same fact), and
+//   x - s s- <= 0  <=>  sqrt(x) < the midpoint of (s-, s)  =>  s-          x - s s+ > 0  <=>  sqrt(x) > the midpoint of (s, s+)  =>  s+
+// (sqrt(x) is never a midpoint).  The two selects are integer clamps of the residuals' bit patterns -- [r > 0] = med3(bits(r), 0,
+// 1) for any non-NaN r -- summed onto bits(s-): s- + 0, + 1 (= s) or + 2 (= s+).  Outside the domain (zero, subnormal-range
+// residuals below 2^-96, +INF, NaN) the result is meaningless: callers branch to __builtin_sqrtf there.  Exhaustively checked
+// against the compiler's correctly rounded sqrtf on MI355X for every f32 in the domain (apd_selftest_sqrt, tests/test_gpu_sqrt.py).
+__device__ __forceinline__ float sqrt_rn_finite(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const int sb = __builtin_bit_cast(int, s);
+    const float s_dn = __builtin_bit_cast(float, sb - 1), s_up = __builtin_bit_cast(float, sb + 1);
+    const int rp = __builtin_bit_cast(int, __builtin_fmaf(-s_dn, s, x));
+    const int rs = __builtin_bit_cast(int, __builtin_fmaf(-s_up, s, x));
+    int up, keep;                                                 // written as max(min(r, 1), 0) the compiler canonicalises the clamps
+    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(up) : "v"(rs));          // back into compare + select pairs (twice the issue cost)
+    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(keep) : "v"(rp));
+    return __builtin_bit_cast(float, (sb - 1) + up + keep);
+}
+
 __device__ __forceinline__ uint32_t band_from_pct(float pct, uint32_t len)
 {
     float p = pct * (float)len;                 // discovery.rs:40, one f32 rounding
@@ -190,6 +211,16 @@ extern template bool launch_systolic<13>(const AlignLaunch &, int, int, bool, hi
 extern template bool launch_systolic<16>(const AlignLaunch &, int, int, bool, hipStream_t);
 extern template bool launch_systolic<20>(const AlignLaunch &, int, int, bool, hipStream_t);
 extern template bool launch_systolic<26>(const AlignLaunch &, int, int, bool, hipStream_t);
+
+// ... and of its strict-mode instantiations <D, C, G, unit penalties, difference form>, in units of their own (dtw_sysx_d<D>.hip).
+template <int D>
+bool launch_systolic_strict(const AlignLaunch &L, int g, int c, hipStream_t stream);
+extern template bool launch_systolic_strict<8>(const AlignLaunch &, int, int, hipStream_t);
+extern template bool launch_systolic_strict<10>(const AlignLaunch &, int, int, hipStream_t);
+extern template bool launch_systolic_strict<13>(const AlignLaunch &, int, int, hipStream_t);
+extern template bool launch_systolic_strict<16>(const AlignLaunch &, int, int, hipStream_t);
+extern template bool launch_systolic_strict<20>(const AlignLaunch &, int, int, hipStream_t);
+extern template bool launch_systolic_strict<26>(const AlignLaunch &, int, int, hipStream_t);
 
 // Wide-band kernel (dtw_wide.h): NW waves per pair; returns false when (NW, C) is not instantiated.
 template <int D>

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void pad_frames_kernel(const float *__restrict
                 const uint32_t k = 4 * q + i;
                 if (k < src_dim) {                                // components src_dim .. dim - 1 stay zero
                     v[i] = fr[k];
-                    nonfinite |= !(__builtin_fabsf(v[i]) < APD_INF);   // NaN or +-INF
+                    nonfinite |= !(__builtin_fabsf(v[i]) < kFeatureBound);   // NaN, +-INF, or so large that a squared distance could overflow
                     part += (double)v[i] * (double)v[i];
                 }
             }
@@ -208,8 +208,9 @@ __global__ __launch_bounds__(256) void pad_frames_kernel(const float *__restrict
         }
         if (live) *reinterpret_cast<float4 *>(dst + e * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
-    // the fast kernels assume finite features (fminf-based select, +INF sentinels, norm expansion): a batch with a NaN or an
-    // infinity anywhere is routed to the literal kernel, where NaN compares false and takes MATCH as in alignments.rs:153-159
+    // the fast kernels assume finite features (fminf-based select, +INF sentinels, norm expansion) and finite squared distances
+    // (sqrt_rn_finite): a batch with a NaN, an infinity or a feature of magnitude >= 2^60 anywhere is routed to the literal kernel,
+    // where NaN compares false and takes MATCH as in alignments.rs:153-159 and an overflowing distance is +INF as on the CPU
     if (__ballot(nonfinite) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flags, 1u);
 }
 
@@ -257,6 +258,33 @@ __global__ void selftest_kernel(int *result)
     ok &= group_from_upper<8>(v, -6.0f, lane % 8) == (lane % 8 == 7 ? -6.0f : (float)(lane + 1));
     const unsigned long long all = __ballot(ok);
     if (lane == 0) *result = (all == ~0ull) ? 1 : 0;
+}
+
+// Exhaustive check of sqrt_rn_finite (dtw_common.h) against the compiler's correctly rounded sqrtf over the bit patterns
+// [first, first + count): out[0] = patterns inside the domain (2^-96 <= x < +INF) where the two differ, out[1] = the first such
+// pattern + 1, out[2..6] = how often the raw v_sqrt_f32 is off by -2 or less, -1, 0, +1, +2 or more ulps there.
+__global__ __launch_bounds__(256) void sqrt_sweep_kernel(uint32_t first, uint64_t count, unsigned long long *out)
+{
+    unsigned long long bad = 0, hist[5] = {0, 0, 0, 0, 0};
+    uint32_t first_bad = 0xFFFFFFFFu;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t bits = first + (uint32_t)e;
+        const float x = __builtin_bit_cast(float, bits);
+        if (!(x >= 0x1p-96f && x < APD_INF)) continue;
+        const float want = __builtin_sqrtf(x), got = sqrt_rn_finite(x), raw = __builtin_amdgcn_sqrtf(x);
+        if (__builtin_bit_cast(uint32_t, want) != __builtin_bit_cast(uint32_t, got)) { ++bad; first_bad = min(first_bad, bits); }
+        const int off = __builtin_bit_cast(int, raw) - __builtin_bit_cast(int, want);
+        ++hist[off <= -2 ? 0 : off >= 2 ? 4 : off + 2];
+    }
+    if (bad) { atomicAdd(&out[0], bad); atomicMin(&out[1], (unsigned long long)first_bad + 1ull); }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) if (hist[k]) atomicAdd(&out[2 + k], hist[k]);
+}
+
+hipError_t launch_sqrt_sweep(uint32_t first, uint64_t count, unsigned long long *d_out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(sqrt_sweep_kernel, dim3(4096), dim3(256), 0, stream, first, count, d_out);
+    return hipGetLastError();
 }
 
 hipError_t launch_selftest(int *d_result, hipStream_t stream)

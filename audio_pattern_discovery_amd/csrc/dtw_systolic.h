@@ -84,7 +84,7 @@ __device__ __forceinline__ float frame_dist(const float (&x)[DN], const float (&
 // adds a penalty that depends on WHICH predecessor won: a near-tie resolved the other way moves the score by percents,
 // so the comparison inputs must be the reference's to the last bit.
 template <int D, int DN>
-__device__ __forceinline__ float frame_dist_strict(const float (&x)[DN], const float (&y)[DN])
+__device__ __forceinline__ float frame_sq_strict(const float (&x)[DN], const float (&y)[DN])
 {
     float t = x[0] - y[0];
     float acc = t * t;                                            // 0.0 + t*t == t*t
@@ -94,7 +94,12 @@ __device__ __forceinline__ float frame_dist_strict(const float (&x)[DN], const f
         const float sq = t * t;
         acc = acc + sq;
     }
-    return __builtin_sqrtf(acc);                                  // correctly rounded (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt)
+    return acc;
+}
+template <int D, int DN>
+__device__ __forceinline__ float frame_dist_strict(const float (&x)[DN], const float (&y)[DN])
+{
+    return __builtin_sqrtf(frame_sq_strict<D, DN>(x, y));         // correctly rounded (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt)
 }
 
 // Squared distance by norm expansion, |x|^2 + |y|^2 - 2 x.y: x[D], y[D] hold the squared norms, and the row frame comes
@@ -217,7 +222,17 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     // G = 8 (two groups per DPP row) is the same case one level down: row_shl instead of wave_shl.
     constexpr bool MASKED_FETCH = HYBRID && (G == 32 || G == 8) && !(APD_ABLATE & 512);
     const int total_r = ((total + U - 1) / U) * U;
-    const int a_end = min(((G + U - 1) / U) * U, total_r);
+    // Strict mode (unit penalties, difference form): the steady-state loop takes square roots with sqrt_rn_finite, whose domain
+    // excludes +INF, so every macro-step in which some lane still holds a sentinel column (j <= 0: tau <= w - (C-1) gl, at most w)
+    // or a row <= 0 (tau < G) stays in the slow phase, whose square root is the compiler's general sequence.
+    int a_steps = G;
+    if (UNIFORM_PEN && !HYBRID) {
+        int w_max = 0;
+#pragma unroll
+        for (int g = 0; g < PPW; ++g) w_max = max(w_max, __builtin_amdgcn_readlane(w, g * G));
+        a_steps = max(G, w_max + 1);
+    }
+    const int a_end = min(((a_steps + U - 1) / U) * U, total_r);
     const int b_end = min(max((min_rows / U) * U, a_end), total_r);
 
     float prev1[C], prev2[C];
@@ -399,6 +414,28 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
 #pragma unroll
                     for (int c = 0; c < C; ++c) d[c] = (APD_ABLATE & 1) ? d[c] : __builtin_amdgcn_sqrtf(d[c]);
                     read_row_at(xs[0], xrows + q * RS);           // the row frame is dead now: fetch the next one under the DP rows
+                } else if (UNIFORM_PEN && !SLOW && !PIPE) {
+                    // Strict mode, steady state.  The difference form of the band kernels IS the reference's arithmetic
+                    // (numerics.rs:114-120 operation for operation); the square root is sqrt_rn_finite (dtw_common.h): v_sqrt_f32 and
+                    // an exact two-sided fix-up, 7 vector ops instead of the 16 of the compiler's general sequence.  Its domain is
+                    // 2^-96 <= d2 < +INF: the steady state sees no sentinel frame (strict_a_end below keeps those macro-steps in the
+                    // slow phase) and no overflow (features >= 2^60 flag the batch for the literal kernel), and a macro-step in
+                    // which some cell's d2 is below 2^-96 (zero included: identical frames) takes the general sequence instead,
+                    // behind one wave-uniform branch.
+                    float d2[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) d2[c] = frame_sq_strict<D, DN>(xs[xa], yf[(r + c) % S]);
+                    float dmin = d2[0];
+#pragma unroll
+                    for (int c = 1; c + 1 < C; c += 2) dmin = __builtin_fminf(__builtin_fminf(dmin, d2[c]), d2[c + 1]);
+                    if (C % 2 == 0) dmin = __builtin_fminf(dmin, d2[C - 1]);
+                    if (__builtin_expect(__ballot(!(dmin >= 0x1p-96f)) != 0ull, 0)) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) d[c] = __builtin_sqrtf(d2[c]);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) d[c] = sqrt_rn_finite(d2[c]);
+                    }
                 } else {
 #pragma unroll
                     for (int c = 0; c < C; ++c)
@@ -471,30 +508,44 @@ __global__ __launch_bounds__(256) void dtw_fused_systolic(const AlignLaunch L)
     }
 }
 
-template <int D, int C, int G>
-static void launch_systolic_cg(const AlignLaunch &L, bool unit, hipStream_t stream)
+// The three instantiations of one (D, C, G) live in two translation units -- dtw_sys_d<D>.hip: hybrid form and the literal select
+// (non-unit penalties); dtw_sysx_d<D>.hip (APD_SYSTOLIC_STRICT_UNIT): strict mode's <.., true, false> -- so that each is
+// compiled once, in parallel, with the scheduler flags measured for its own instruction mix (csrc/Makefile).
+template <int D, int C, int G, bool UNIFORM_PEN, bool HYBRID>
+static void launch_systolic_kernel(const AlignLaunch &L, hipStream_t stream)
 {
     constexpr int PPW = 64 / G;
     constexpr int WPT = kSlotsPerTile / (4 * PPW);
     const uint32_t tiles8 = (L.n_tiles + 7u) / 8u * 8u;
-    const dim3 grid(tiles8 * WPT), block(256);
-    // unit penalties: the fast select, either distance form; anything else: literal select on strict (bit-faithful) distances
-    if (!unit) hipLaunchKernelGGL((dtw_fused_systolic<D, C, G, false, false>), grid, block, 0, stream, L);
-    else if (L.hybrid) hipLaunchKernelGGL((dtw_fused_systolic<D, C, G, true, true>), grid, block, 0, stream, L);
-    else hipLaunchKernelGGL((dtw_fused_systolic<D, C, G, true, false>), grid, block, 0, stream, L);
+    hipLaunchKernelGGL((dtw_fused_systolic<D, C, G, UNIFORM_PEN, HYBRID>), dim3(tiles8 * WPT), dim3(256), 0, stream, L);
 }
 
+// C = 9 keeps 10 column frames per lane in registers: only for D <= 13 (max_cells_per_lane)
+#define APD_SYSTOLIC_GEOMETRIES(X) \
+    X(8, 5) X(8, 7) X(8, 9) X(16, 2) X(16, 3) X(16, 5) X(16, 7) X(16, 9) X(32, 5) X(32, 7) X(32, 9) X(64, 3) X(64, 5) X(64, 7) X(64, 9)
+
+#ifdef APD_SYSTOLIC_STRICT_UNIT
 template <int D>
-bool launch_systolic(const AlignLaunch &L, int g, int c, bool unit, hipStream_t stream)
+bool launch_systolic_strict(const AlignLaunch &L, int g, int c, hipStream_t stream)
 {
-    // C = 9 keeps 10 column frames per lane in registers: only for D <= 13 (max_cells_per_lane)
-#define APD_CASE(GG, CC) if constexpr (CC <= max_cells_per_lane(D)) { if (g == GG && c == CC) { launch_systolic_cg<D, CC, GG>(L, unit, stream); return true; } }
-    APD_CASE(8, 5) APD_CASE(8, 7) APD_CASE(8, 9)
-    APD_CASE(16, 2) APD_CASE(16, 3) APD_CASE(16, 5) APD_CASE(16, 7) APD_CASE(16, 9)
-    APD_CASE(32, 5) APD_CASE(32, 7) APD_CASE(32, 9)
-    APD_CASE(64, 3) APD_CASE(64, 5) APD_CASE(64, 7) APD_CASE(64, 9)
+#define APD_CASE(GG, CC) if constexpr (CC <= max_cells_per_lane(D)) { if (g == GG && c == CC) { launch_systolic_kernel<D, CC, GG, true, false>(L, stream); return true; } }
+    APD_SYSTOLIC_GEOMETRIES(APD_CASE)
 #undef APD_CASE
     return false;
 }
+#else
+template <int D>
+bool launch_systolic(const AlignLaunch &L, int g, int c, bool unit, hipStream_t stream)
+{
+    // unit penalties: the fast select, either distance form; anything else: literal select on strict (bit-faithful) distances
+    if (unit && !L.hybrid) return launch_systolic_strict<D>(L, g, c, stream);
+#define APD_CASE(GG, CC) if constexpr (CC <= max_cells_per_lane(D)) { if (g == GG && c == CC) { \
+        if (!unit) launch_systolic_kernel<D, CC, GG, false, false>(L, stream); else launch_systolic_kernel<D, CC, GG, true, true>(L, stream); \
+        return true; } }
+    APD_SYSTOLIC_GEOMETRIES(APD_CASE)
+#undef APD_CASE
+    return false;
+}
+#endif
 
 }  // namespace apd

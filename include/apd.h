@@ -114,6 +114,13 @@ int apd_set_variant(apd_context *ctx, int variant);
 int apd_set_distance_mode(apd_context *ctx, int mode, float tau);
 /* Device self-test of the cross-lane primitives the kernels rely on (DPP wave shifts). */
 int apd_selftest(apd_context *ctx);
+/* TEST HOOK: strict mode's square root (v_sqrt_f32 + an exact two-sided fix-up, csrc/dtw_common.h sqrt_rn_finite) against the
+ * compiler's correctly rounded sqrtf (= Rust's f32::sqrt, numerics.rs:119) for the `count` (<= 2^32) consecutive f32 bit patterns
+ * from first_bits, restricted to its domain 2^-96 <= x < +INF: *mismatches = how many differ (must be 0), *first_mismatch the
+ * first such pattern, raw_ulp_hist[5] (may be NULL) = how often the bare v_sqrt_f32 is off by <= -2, -1, 0, +1, >= +2 ulps.
+ * The whole f32 range takes about a second (tests/test_gpu_sqrt.py). */
+int apd_selftest_sqrt(apd_context *ctx, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint32_t *first_mismatch,
+                      uint64_t *raw_ulp_hist);
 /* TEST HOOK (fault injection): the next alignment launches leave the last `drop_tiles` tiles of every kernel class
  * unprocessed, as a launch that is cut short would.  0 = off.  Exists so that the poison / APD_ERR_INCOMPLETE path can
  * be tested (tests/test_gpu_dtw.py); never set it in production. */

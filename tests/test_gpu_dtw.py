@@ -168,6 +168,38 @@ def test_kat_through_the_gpu(ctx):
     assert a.score() == pytest.approx(0.2, rel=1e-6)   # SURVEY.md §4 KAT: cell (n-1, m-1), not (n, m)
 
 
+@pytest.mark.parametrize("dim", [1, 8, 13, 26])
+@pytest.mark.parametrize("mode,variant", [("hybrid", 0), ("exact", 0), ("strict", 0), ("hybrid", 1)])
+def test_kat_delete_insert_tie_below_match_through_the_gpu(ctx, mode, variant, dim):
+    """alignments.rs:153-159, hand-derived in tests/test_oracle.py::test_kat_delete_insert_tie_below_match_takes_match:
+    x = [0,1,0,0], y = [1,0,1,0] -> cell (3,3) has Dl == I = 1 < M = 2 and takes MATCH: score 3/8 = 0.375 (a minimum-rule DTW: 0.25).
+    Integer features: every distance form is exact, so EVERY mode and kernel family must return exactly 0.375 -- through
+    Alignment::construct_alignment (apd_align_pair) and through AlignmentWorkers::align_all, with a binding band (band kernels)
+    and a full one (strip kernels)."""
+    from audio_pattern_discovery_amd.alignments import Alignment, AlignmentParams, AlignmentWorkers, NDSequence
+    from audio_pattern_discovery_amd.discovery import Discovery
+    x, y = np.zeros((4, dim), np.float32), np.zeros((4, dim), np.float32)
+    x[:, 0], y[:, 0] = [0, 1, 0, 0], [1, 0, 1, 0]
+    ctx.set_distance_mode(mode)
+    ctx.set_variant(variant)
+    try:
+        for band in (0, 10):
+            a = Alignment(ctx)
+            a.construct_alignment(x, y, AlignmentParams.default(band))
+            assert a.score() == 0.375
+            a.construct_alignment(y, x, AlignmentParams.default(band))
+            assert a.score() == 0.375
+        seqs = [NDSequence(x), NDSequence(y)] * 9                  # 18 sequences: more than one tile, every ordered pair
+        for pct in (0.0, 1.0):
+            got = AlignmentWorkers.new(seqs, ctx).align_all(Discovery(warping_band_percentage=pct)).reshape(18, 18)
+            for i in range(18):
+                for j in range(18):
+                    assert got[i, j] == (0.0 if (i - j) % 2 == 0 else 0.375), (pct, i, j, got[i, j])
+    finally:
+        ctx.set_distance_mode("hybrid")
+        ctx.set_variant(0)
+
+
 def test_sharded_tiles_equal_single_launch(ctx, apd, oracle):
     """world=3 slabs computed one after the other on one GPU, concatenated as an all-gather would,
     then unpacked, must equal the single-launch matrix (the multi-GPU data path minus RCCL)."""

@@ -60,6 +60,29 @@ def test_kat_tie_goes_to_match_even_if_not_minimal(oracle):
     assert oracle.dtw_pair(x, y, 10) == pytest.approx(4.0 / 6.0, abs=1e-7)
 
 
+def test_kat_delete_insert_tie_below_match_takes_match(oracle):
+    """THE quirk of alignments.rs:153-159: `Dl == I < M` fails both strict tests and lands in the MATCH branch although MATCH is
+    the largest predecessor.  Derived by hand (D = 1, unit penalties, full band), x = [0,1,0,0], y = [1,0,1,0]:
+        d = |x_i - y_j|:   row 1: 1 0 1 0     row 2: 0 1 0 1     row 3: 1 0 1 0
+        D[1][1] = 0+1 = 1   D[1][2] = Dl 1+0 = 1   D[1][3] = Dl 1+1 = 2
+        D[2][1] = I 1+0 = 1 D[2][2] = (1,1,1 tie) M 1+1 = 2   D[2][3] = M=1,I=2,Dl=2 -> M 1+0 = 1
+        D[3][1] = I 1+1 = 2 D[3][2] = M=1,I=2,Dl=2 -> M 1+0 = 1
+        D[3][3]: M = D[2][2] = 2, I = D[2][3] = 1, Dl = D[3][2] = 1  ->  Dl == I < M  ->  MATCH: 2 + 1 = 3
+    score = D[3][3] / (4+4) = 0.375.  A DTW that takes the minimum predecessor gives (1 + 1) / 8 = 0.25.
+    The swapped pair has the transposed costs and the same tie at (3,3): 0.375 too."""
+    x, y = col([0, 1, 0, 0]), col([1, 0, 1, 0])
+    for band in (10, 4, 0):                         # band 0 -> w = 2: cell (1,3) is not visited, nothing on the path changes
+        for hm in (False, True):
+            assert oracle.dtw_pair(x, y, band, hashmap=hm) == 0.375
+            assert oracle.dtw_pair(y, x, band, hashmap=hm) == 0.375
+        assert float(npr.dtw_pair(x, y, band)) == 0.375
+        assert float(npr.dtw_pair(y, x, band)) == 0.375
+    # the same values in component 0 of 13-dimensional frames (what the band kernels are instantiated for)
+    x13, y13 = np.zeros((4, 13), np.float32), np.zeros((4, 13), np.float32)
+    x13[:, 0], y13[:, 0] = x[:, 0], y[:, 0]
+    assert oracle.dtw_pair(x13, y13, 10) == 0.375
+
+
 def test_kat_band_is_asymmetric_and_widened(oracle):
     # w = max(band, |n-m|) + 2 ; j in [max(i-w,1), min(i+w, m+1))  -> j-i in [-w, w-1]
     assert oracle.dtw_cells(5, 5, 0) == sum(min(i + 2, 6) - max(i - 2, 1) for i in range(1, 6))

@@ -7,6 +7,6 @@ for a in "$@"; do
 done
 wait
 for a in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /root/repo/build/ablate/libapd_hip_abl$a.so apd_api.o dtw_generic.o dtw_sys_d8.o dtw_sys_d10.o /tmp/t/abl_$a.o dtw_sys_d16.o dtw_sys_d20.o dtw_sys_d26.o dtw_wf_d8.o dtw_wf_d10.o dtw_wf_d13.o dtw_wf_d16.o dtw_wf_d20.o dtw_wf_d26.o clustering.o companions.o comm.o formats.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /root/repo/build/ablate/libapd_hip_abl$a.so apd_api.o dtw_generic.o dtw_sys_d8.o dtw_sys_d10.o /tmp/t/abl_$a.o dtw_sys_d16.o dtw_sys_d20.o dtw_sys_d26.o dtw_sysx_d8.o dtw_sysx_d10.o dtw_sysx_d16.o dtw_sysx_d20.o dtw_sysx_d26.o ${SYSX13:-dtw_sysx_d13.o} dtw_wf_d8.o dtw_wf_d10.o dtw_wf_d13.o dtw_wf_d16.o dtw_wf_d20.o dtw_wf_d26.o clustering.o companions.o comm.o formats.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 done
 ls -la /root/repo/build/ablate/
