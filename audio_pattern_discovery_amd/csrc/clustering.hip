@@ -8,11 +8,17 @@
 //   are recomputed from the raw distances in EXACTLY the reference's order (x ascending over Cp, y ascending over Cq,
 //   one running f32 accumulator, clustering.rs:157-169) from sorted member lists, so every linkage -- and with it the
 //   whole merge sequence, including the p/q order of mathematically tied directed pairs that the reference settles
-//   by rounding noise -- is bit-identical to the literal algorithm.  Each merge is three launches: row minima (a
-//   cached best ordered pair per live row; only rows whose cache went stale re-read their row of S), one workgroup
-//   that reduces the row minima, applies merge_clusters and merges the two member lists, and one pass that rebuilds
-//   the new cluster's row and column and patches the other rows' caches.  Exact ties resolve to the lowest (id_p, id_q): what the reference does when its HashSet happens
-//   to iterate in ascending order (clustering.rs:180-187); any other order is equally "reference".
+//   by rounding noise -- is bit-identical to the literal algorithm.  Each merge is THREE launches (round 3: eight):
+//     upgma_select_kernel   row minima of the rows whose cached best pair went stale (a compact list), then -- in the
+//                           workgroup that finishes last -- the global arg-min, merge_clusters, the merged member list;
+//     upgma_chain_kernel    every chain of the new cluster's row and column of S that one lane or one wavefront sums
+//                           whole; long chains get their segments allocated (atomic bump) and predicted here;
+//     upgma_segment_kernel  the segments' integer maps, and -- in the wavefront that finishes a chain's last segment --
+//                           the in-order commit of that chain.
+//   No workgroup ever waits for another one: "last to arrive does the serial part" (an atomic counter and a fence), so the
+//   kernels cannot deadlock whatever the scheduler does.  Exact ties resolve to the lowest (id_p, id_q): what the
+//   reference does when its HashSet happens to iterate in ascending order (clustering.rs:180-187); any other order is
+//   equally "reference".
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -130,6 +136,22 @@ __device__ __forceinline__ bool better(const Cand &a, const Cand &b)
     return false;
 }
 
+// The best candidate of a workgroup (blockDim.x a power of two, <= 1024), valid in thread 0: a plain tree over LDS.  (A version
+// that reduced inside the wavefronts with five independent field shuffles first returned a winner whose (l, idp, idq) came from one
+// candidate and (sp, sq) from another when two candidates of one lane tied in l -- found by the tie-laden matrices of
+// tests/test_gpu_clustering.py; the tree has no such failure mode and costs ~2 us.)
+__device__ __forceinline__ Cand block_best(Cand best, Cand *red /* blockDim.x entries of LDS */)
+{
+    __syncthreads();                                                      // `red` may still be read from the previous call
+    red[threadIdx.x] = best;
+    __syncthreads();
+    for (int s = (int)blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s && better(red[threadIdx.x + s], red[threadIdx.x])) red[threadIdx.x] = red[threadIdx.x + s];
+        __syncthreads();
+    }
+    return red[0];
+}
+
 struct UpgmaState {
     const float *d;           // [n][n] raw distances (read only)
     float *S;                 // [n][n] directed cluster sums (slot-indexed)
@@ -137,18 +159,28 @@ struct UpgmaState {
     uint32_t *mstart, *mcount;// [n] list of the cluster held by a slot
     uint32_t *pool_used;
     uint32_t *last_sp;        // slot of the cluster created by the latest merge (0xFFFFFFFF: none)
-    float *size;              // [n] member counts as f32 (the reference counts in f32, clustering.rs:154-166)
+    float *size;              // [n] member counts as f32 (the reference counts in f32, clustering.rs:154-166); 0: the slot is dead
     uint32_t *id;             // [n] cluster id held by the slot
-    uint32_t *live;           // [n_live] slots still holding a root, ascending slot order is irrelevant
+    uint32_t *live;           // [n_live] slots still holding a root (order irrelevant); pos[slot] = its index in here
+    uint32_t *pos;
     uint32_t *n_live;
     Cand *rbest;              // [n] cached best ordered pair of the row held by a slot
-    uint32_t *rscan;          // [n] 1: the cache of this row is stale, rescan it
+    float *rb_l;              // [n] its linkage alone (+INF for a dead slot): what the global arg-min streams over
+    uint32_t *big;            // [n_big] live slots holding a cluster of two or more members (order irrelevant); bpos[slot] = index or ~0
+    uint32_t *bpos;
+    uint32_t *n_big;
+    uint32_t *rscan;          // [n] 1: the cache of this row is stale and the slot is on the stale list
+    uint32_t *stale;          // [n] slots whose row must be re-scanned by the next select launch
+    uint32_t *n_stale;
+    uint32_t *arrive;         // workgroups of the running select launch that have finished their rows
+    uint32_t *r_pending;      // 1: R[.][last_sp] += R[.][last_sq] of the latest merge has not been applied yet
     uint32_t *last_sq;        // slot that died in the latest merge
     apd_cluster_op *ops;      // [n]
     uint32_t *n_ops;
     float *R;                 // [n][n] R[x][slot]: approximate sum of d[x][y] over the members y of the cluster in `slot`
-    uint32_t *item_start;     // [2 n + 1] first work item of every chain of the current merge
-    uint32_t *item_count;     // [2 n] work items of every chain
+    uint32_t *item_start;     // [2 n] first work item (segment) of a segmented chain of the current merge
+    uint32_t *item_chain;     // [max_items] chain of every work item
+    uint32_t *seg_done;       // [2 n] finished segments of a segmented chain
     float *packed;            // contiguous copies of the segments the commit pass is likely to re-walk (nullptr: off)
     uint32_t *pack_used;      // bump allocator of `packed`, reset per merge
     uint32_t pack_capacity;   // floats
@@ -156,77 +188,148 @@ struct UpgmaState {
     SegRes *seg;              // [max_items] segment results of the current merge
     uint32_t *n_items;
     uint32_t *done;           // set once the loop condition of clustering.rs:104 fails
+    unsigned long long *dbg;  // APD_DEBUG_UPGMA_TIMING: [n][10] wall_clock64 stamps per merge (nullptr: off)
     float threshold;
     uint32_t n;
 };
 
-// Row minima: one workgroup per live row whose cached best pair is stale (new cluster, or its best column just
-// merged/died); the others keep their cache.  A full scan reads one row of S: the per-merge HBM traffic is
-// (stale rows) x 4c bytes instead of 4c^2.
-__global__ __launch_bounds__(1024) void upgma_rowmin_kernel(UpgmaState st)
-{
-    __shared__ Cand red[1024];
-    if (*st.done != 0) return;
-    const uint32_t nl = *st.n_live;
-    for (uint32_t r = blockIdx.x; r < nl; r += gridDim.x) {
-        const uint32_t sp = st.live[r];
-        if (st.rscan[sp] == 0) continue;                                  // block-uniform
-        Cand best{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu, sp, sp};
-        const float size_p = st.size[sp];
-        const uint32_t idp = st.id[sp];
-        const float *row = st.S + (uint64_t)sp * st.n;
-        // A scan is a chain of dependent loads (live[c] -> S, size, id of that slot): 1024 threads and four columns in flight
-        // per thread keep a 15000-column row at a handful of round trips (256 threads, one column each: 58 us per merge at cfg 5).
-        constexpr uint32_t kIlp = 4;
-        for (uint32_t c0 = threadIdx.x; c0 < nl; c0 += kIlp * blockDim.x) {
-            uint32_t sq[kIlp];
-            float v[kIlp], sz[kIlp];
-            uint32_t idq[kIlp];
-#pragma unroll
-            for (uint32_t u = 0; u < kIlp; ++u) { const uint32_t c = c0 + u * blockDim.x; sq[u] = c < nl ? st.live[c] : sp; }
-#pragma unroll
-            for (uint32_t u = 0; u < kIlp; ++u) { v[u] = row[sq[u]]; sz[u] = st.size[sq[u]]; idq[u] = st.id[sq[u]]; }
-#pragma unroll
-            for (uint32_t u = 0; u < kIlp; ++u) {
-                if (sq[u] == sp) continue;                                // target_i != target_j (clustering.rs:182); also the padding
-                const float denom = size_p * sz[u];                       // size_x * size_y (:169)
-                const Cand cnd{v[u] / denom, idp, idq[u], sp, sq[u]};
-                if (better(cnd, best)) best = cnd;
-            }
-        }
-        red[threadIdx.x] = best;
-        __syncthreads();
-        for (int s = (int)blockDim.x / 2; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s && better(red[threadIdx.x + s], red[threadIdx.x])) red[threadIdx.x] = red[threadIdx.x + s];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) { st.rbest[sp] = red[0]; st.rscan[sp] = 0; }
-        __syncthreads();
-    }
-}
-
-// One workgroup: final arg-min, merge_clusters (clustering.rs:134-141), sums of the new cluster, the op record.
-__global__ __launch_bounds__(1024) void upgma_merge_kernel(UpgmaState st)
+// Launch 1 of a merge.  Every workgroup: (a) its share of R[x][sp'] += R[x][sq'] of the PREVIOUS merge (R only predicts
+// binades: nothing in this launch reads it); (b) row minima of the stale rows it draws from the compact stale list -- a
+// direct scan over all n slots (S row, size, id: coalesced, independent loads; dead slots have size 0), no indirection
+// through the live list.  The workgroup that arrives last then does what used to be a launch of its own: global arg-min over
+// the cached row minima, merge_clusters (clustering.rs:134-141), the merged member list, the op record.
+__global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
 {
     __shared__ Cand red[1024];
     __shared__ Cand win;
+    __shared__ uint32_t is_last;
     if (*st.done != 0) return;
+    const uint32_t n = st.n;
+    const unsigned long long t_entry = st.dbg ? wall_clock64() : 0ull;
+    // every scalar this workgroup needs, loaded together (one memory round trip, not one per dependent step)
+    const uint32_t pending = *st.r_pending, sp0 = *st.last_sp, sq0 = *st.last_sq, ns = *st.n_stale;
+    const uint32_t first_stale = st.stale[min(blockIdx.x, n - 1)];       // meaningful if blockIdx.x < ns
+    if (pending != 0u) {
+        // the R update is dealt from the far end of the grid: the stale rows start at workgroup 0
+        for (uint32_t x = (gridDim.x - 1u - blockIdx.x) * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
+            float *r = st.R + (uint64_t)x * n;
+            r[sp0] = r[sp0] + r[sq0];
+        }
+    }
+    for (uint32_t r = blockIdx.x; r < ns; r += gridDim.x) {
+        const uint32_t sp = r == blockIdx.x ? first_stale : st.stale[r];
+        Cand best{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu, sp, sp};
+        const float size_p = st.size[sp];
+        const uint32_t idp = st.id[sp];
+        const float *row = st.S + (uint64_t)sp * n;
+        // the row's best column, tracked as three scalars (linkage, id of the column's cluster, column slot): idp and sp are the
+        // row's own.  Same order as `better`: smaller linkage, then smaller idq; +INF and NaN linkages never win.
+        float bl = __builtin_inff();
+        uint32_t bidq = 0xFFFFFFFFu, bsq = sp;
+        auto consider = [&](uint32_t c, float v, float sz, uint32_t idq) __attribute__((always_inline)) {
+            if (c >= n || c == sp || sz == 0.0f) return;                  // target_i != target_j (clustering.rs:182); dead slots
+            const float l = v / (size_p * sz);                            // size_x * size_y (:169)
+            const bool take = (l < __builtin_inff()) && (l < bl || (l == bl && idq < bidq));
+            bl = take ? l : bl; bidq = take ? idq : bidq; bsq = take ? c : bsq;
+        };
+        if ((n & 3u) == 0u) {
+            // 16-byte loads, every load of the row issued before the first use: one memory round trip per 16 K columns
+            constexpr uint32_t kVec = 4;
+            const float4 *row4 = reinterpret_cast<const float4 *>(row), *sz4 = reinterpret_cast<const float4 *>(st.size);
+            const uint4 *id4 = reinterpret_cast<const uint4 *>(st.id);
+            const uint32_t n4 = n >> 2;
+            for (uint32_t q0 = threadIdx.x; q0 < n4; q0 += kVec * blockDim.x) {
+                float4 v[kVec], z[kVec];
+                uint4 i[kVec];
+#pragma unroll
+                for (uint32_t u = 0; u < kVec; ++u) { const uint32_t q = min(q0 + u * blockDim.x, n4 - 1); v[u] = row4[q]; z[u] = sz4[q]; i[u] = id4[q]; }
+#pragma unroll
+                for (uint32_t u = 0; u < kVec; ++u) {
+                    const uint32_t q = q0 + u * blockDim.x;
+                    if (q >= n4) continue;
+                    consider(4 * q + 0, v[u].x, z[u].x, i[u].x); consider(4 * q + 1, v[u].y, z[u].y, i[u].y);
+                    consider(4 * q + 2, v[u].z, z[u].z, i[u].z); consider(4 * q + 3, v[u].w, z[u].w, i[u].w);
+                }
+            }
+        } else {
+            constexpr uint32_t kIlp = 4;
+            for (uint32_t c0 = threadIdx.x; c0 < n; c0 += kIlp * blockDim.x) {
+                float v[kIlp], sz[kIlp];
+                uint32_t idq[kIlp];
+#pragma unroll
+                for (uint32_t u = 0; u < kIlp; ++u) {
+                    const uint32_t c = min(c0 + u * blockDim.x, n - 1);
+                    v[u] = row[c]; sz[u] = st.size[c]; idq[u] = st.id[c];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kIlp; ++u) consider(c0 + u * blockDim.x, v[u], sz[u], idq[u]);
+            }
+        }
+        best = bl < __builtin_inff() ? Cand{bl, idp, bidq, sp, bsq} : best;
+        best = block_best(best, red);
+        if (threadIdx.x == 0) { st.rbest[sp] = best; st.rb_l[sp] = best.l; st.rscan[sp] = 0; }
+    }
+    // ---- who is last?  (the classic fence + counter: every workgroup's writes above are visible to the one that sees the full count)
+    const unsigned long long t_rows = st.dbg ? wall_clock64() : 0ull;
+    // ONE agent-scope fence per workgroup, behind the barrier (on a multi-XCD part a release fence writes the XCD's L2 back: sixteen
+    // wavefronts doing it each was most of this launch's 34 us at n = 4096)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        is_last = atomicAdd(st.arrive, 1u) == gridDim.x - 1u ? 1u : 0u;
+        __threadfence();
+    }
+    __syncthreads();
+    if (is_last == 0u) return;
+    const unsigned long long t_last = st.dbg ? wall_clock64() : 0ull;
+    if (threadIdx.x == 0) { *st.arrive = 0u; *st.n_stale = 0u; *st.r_pending = 0u; *st.n_items = 0u; *st.pack_used = 0u; }
+    // global arg-min, two passes over the linkages alone (coalesced, independent loads): the smallest value, then `better` among
+    // the rows that hold it (its tie rule needs their ids; almost always a single row)
+    __shared__ float lmin_s[16];
+    float lmin = __builtin_inff();
+    constexpr uint32_t kAhead = 8;                                        // loads in flight per thread
+    for (uint32_t c0 = threadIdx.x; c0 < n; c0 += kAhead * blockDim.x) {
+        float v[kAhead];
+#pragma unroll
+        for (uint32_t u = 0; u < kAhead; ++u) v[u] = st.rb_l[min(c0 + u * blockDim.x, n - 1)];   // a clamped repeat changes no minimum
+#pragma unroll
+        for (uint32_t u = 0; u < kAhead; ++u) lmin = __builtin_fminf(lmin, v[u]);               // NaN never wins (fminf drops it)
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) lmin = __builtin_fminf(lmin, __shfl_xor(lmin, o));
+    if ((threadIdx.x & 63) == 0) lmin_s[threadIdx.x >> 6] = lmin;
+    __syncthreads();
+    lmin = lmin_s[0];
+    for (uint32_t k2 = 1; k2 < (blockDim.x >> 6); ++k2) lmin = __builtin_fminf(lmin, lmin_s[k2]);
+    // ... then, among the rows that hold it, the lowest (idp, idq) -- tracked as scalars plus the row, the winner's record read
+    // back once.  (Carrying a whole Cand through `if (better(cc, best)) best = cc` here was compiled into a partial assignment:
+    // (l, idp, idq) of one row with (sp, sq) of another when a thread met two tied rows -- caught by the tie-laden matrices of
+    // tests/test_gpu_clustering.py.)
+    uint32_t bidp = 0xFFFFFFFFu, bidq = 0xFFFFFFFFu, brow = 0xFFFFFFFFu;
+    if (lmin < __builtin_inff())
+        for (uint32_t c0 = threadIdx.x; c0 < n; c0 += kAhead * blockDim.x) {
+            float v[kAhead];
+#pragma unroll
+            for (uint32_t u = 0; u < kAhead; ++u) v[u] = st.rb_l[min(c0 + u * blockDim.x, n - 1)];   // second pass: L2 hits
+#pragma unroll
+            for (uint32_t u = 0; u < kAhead; ++u) {
+                const uint32_t c = c0 + u * blockDim.x;
+                if (c < n && v[u] == lmin) {
+                    const uint32_t ip = st.rbest[c].idp, iq = st.rbest[c].idq;
+                    const bool take = ip < bidp || (ip == bidp && iq < bidq);
+                    bidp = take ? ip : bidp; bidq = take ? iq : bidq; brow = take ? c : brow;
+                }
+            }
+        }
     Cand best{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0};
-    {
-        const uint32_t nl0 = *st.n_live;
-        for (uint32_t c = threadIdx.x; c < nl0; c += blockDim.x) { const Cand cc = st.rbest[st.live[c]]; if (better(cc, best)) best = cc; }
-    }
-    red[threadIdx.x] = best;
+    if (brow != 0xFFFFFFFFu) best = st.rbest[brow];
+    best = block_best(best, red);
+    if (threadIdx.x == 0) win = best;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s && better(red[threadIdx.x + s], red[threadIdx.x])) red[threadIdx.x] = red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) win = red[0];
-    __syncthreads();
+    const unsigned long long t_argmin = st.dbg ? wall_clock64() : 0ull;
     const Cand w = win;
     const uint32_t t = *st.n_ops;
-    const uint32_t k = st.n + t;                                          // parents.len() (:135)
+    const uint32_t k = n + t;                                             // parents.len() (:135)
     const uint32_t nl = *st.n_live;
     if (w.idp == 0xFFFFFFFFu) {
         // no linkage below +INF: the reference keeps min_merge = (0, 0) (clustering.rs:179) and merges it
@@ -238,11 +341,15 @@ __global__ __launch_bounds__(1024) void upgma_merge_kernel(UpgmaState st)
         }
         return;
     }
-    // new cluster k lives in slot sp; slot sq dies.  Merge the two sorted member lists into a fresh one.
+    // new cluster k lives in slot sp; slot sq dies.  Everything the bookkeeping needs is loaded up front (independent loads: one
+    // round trip instead of a dozen dependent ones in a single thread).
+    const uint32_t msp = st.mstart[w.sp], msq = st.mstart[w.sq], cp = st.mcount[w.sp], cq = st.mcount[w.sq], used = *st.pool_used;
+    const float zp = st.size[w.sp], zq = st.size[w.sq];
+    const uint32_t at = st.pos[w.sq], tail = st.live[nl - 1];
+    // merge the two sorted member lists into a fresh one
     {
-        const uint32_t *lp = st.pool + st.mstart[w.sp], *lq = st.pool + st.mstart[w.sq];
-        const uint32_t cp = st.mcount[w.sp], cq = st.mcount[w.sq];
-        uint32_t *out = st.pool + *st.pool_used;
+        const uint32_t *lp = st.pool + msp, *lq = st.pool + msq;
+        uint32_t *out = st.pool + used;
         for (uint32_t i = threadIdx.x; i < cp + cq; i += blockDim.x) {
             const bool from_p = i < cp;
             const uint32_t v = from_p ? lp[i] : lq[i - cp];
@@ -252,30 +359,38 @@ __global__ __launch_bounds__(1024) void upgma_merge_kernel(UpgmaState st)
             out[(from_p ? i : i - cp) + lo] = v;
         }
     }
-    // drop sq from the live list (its order is irrelevant): every thread scans a stride, the finder swaps in the tail
-    {
-        const uint32_t tail = st.live[nl - 1];
-        __syncthreads();
-        for (uint32_t c = threadIdx.x; c < nl; c += blockDim.x)
-            if (st.live[c] == w.sq) st.live[c] = tail;
-    }
-    __syncthreads();
     if (threadIdx.x == 0) {
+        if (st.dbg) {
+            unsigned long long *g = st.dbg + (uint64_t)t * 10;
+            g[0] = t_entry; g[1] = t_rows; g[2] = t_last; g[3] = t_argmin; g[4] = wall_clock64(); g[5] = ns; g[6] = cp + cq;
+        }
         uint32_t op;
-        const uint32_t n = st.n;
         if (w.idp < n && w.idq < n) op = APD_SEQUENCE2SEQUENCE;           // clustering.rs:193-201
         else if (w.idp >= n && w.idq >= n) op = APD_CLUSTER2CLUSTER;
         else if (w.idp >= n && w.idq < n) op = APD_CLUSTER2SEQUENCE;
         else op = APD_SEQUENCE2CLUSTER;
         st.ops[t] = apd_cluster_op{w.idp, w.idq, k, w.l, op};
         *st.n_ops = t + 1;
-        st.size[w.sp] = st.size[w.sp] + st.size[w.sq];
+        st.size[w.sp] = zp + zq;
+        st.size[w.sq] = 0.0f;                                             // dead: skipped by every scan
+        st.rb_l[w.sq] = __builtin_inff();
+        {   // the clusters of two or more members: sp joins (if new), sq leaves (if it was one)
+            uint32_t nb = *st.n_big;
+            const uint32_t bq = st.bpos[w.sq];
+            if (st.bpos[w.sp] == 0xFFFFFFFFu) { st.big[nb] = w.sp; st.bpos[w.sp] = nb; ++nb; }
+            if (bq != 0xFFFFFFFFu) { const uint32_t tb = st.big[nb - 1]; st.big[bq] = tb; st.bpos[tb] = bq; st.bpos[w.sq] = 0xFFFFFFFFu; --nb; }
+            *st.n_big = nb;
+        }
         st.id[w.sp] = k;
-        const uint32_t used = *st.pool_used, cnt = st.mcount[w.sp] + st.mcount[w.sq];
-        st.mstart[w.sp] = used; st.mcount[w.sp] = cnt; *st.pool_used = used + cnt;
+        st.mstart[w.sp] = used; st.mcount[w.sp] = cp + cq; *st.pool_used = used + cp + cq;
         *st.last_sp = w.sp; *st.last_sq = w.sq;
-        st.rscan[w.sp] = 1;                                               // the new cluster's row is new
+        *st.r_pending = 1u;
+        // drop sq from the live list (its order is irrelevant): the tail moves into its place
+        st.live[at] = tail; st.pos[tail] = at;
         *st.n_live = nl - 1;
+        st.rscan[w.sp] = 1;                                               // the new cluster's row is new
+        st.stale[0] = w.sp;
+        *st.n_stale = 1u;
         if (nl - 1 <= 1 || !(w.l < st.threshold)) *st.done = 1;           // while n_clusters > 1 && distance < threshold (:104)
     }
 }
@@ -513,9 +628,10 @@ __device__ Fn segment_fn(const GatherSrc src, uint32_t lane, uint64_t begin, uin
 // bit-identical to the sequential chain either way; the speculation only decides how fast it is reached.
 namespace {
 
-constexpr uint32_t kSegElems = 4096;             // target elements per segment
-constexpr uint32_t kLaneChain = 2048;            // a SINGLETON against a new cluster of up to this many members: one lane, the literal loop
+constexpr uint32_t kSegElems = 4096;             // target elements per segment (2048 .. 16384 measured: 4096 / 8192 within 2 % of each other, 1024 twice as slow)
 constexpr uint32_t kShortChain = 2 * kSegElems;  // other chains up to this length are walked whole by one wavefront
+constexpr uint32_t kLaneChain = 2048;            // a SINGLETON against a new cluster of up to this many members: one lane, the literal loop
+
 
 struct Chain {
     const uint32_t *lx, *ly;
@@ -523,7 +639,7 @@ struct Chain {
     uint32_t slot_y;        // slot of the cluster the inner index runs over (its column of R predicts the row sums)
     uint32_t s, dir;        // the other cluster's slot; dir 0: S[sp][s], dir 1: S[s][sp]
     uint32_t rps, nseg;     // rows per segment, segments (0: skipped chain, 1: walked whole)
-    bool lane_chain;        // a singleton's chain: summed by one lane of upgma_short_kernel; otherwise by the segment / commit kernels
+    bool lane_chain;        // a singleton's chain: summed by one lane of the chain launch's group wavefronts
 };
 
 __device__ __forceinline__ Chain get_chain(const UpgmaState &st, uint32_t w, uint32_t sp)
@@ -560,67 +676,31 @@ __device__ __forceinline__ void finish_chain(const UpgmaState &st, const Chain &
         st.S[(uint64_t)c.s * st.n + sp] = acc;
         // row s: its cached best pair survives unless it pointed at one of the two merged slots; the new entry may beat it
         const Cand old = st.rbest[c.s];
-        if (old.sq == sp || old.sq == *st.last_sq) st.rscan[c.s] = 1;
-        else {
+        if (old.sq == sp || old.sq == *st.last_sq) {
+            if (atomicExch(&st.rscan[c.s], 1u) == 0u) st.stale[atomicAdd(st.n_stale, 1u)] = c.s;   // re-scanned by the next select launch
+        } else {
             const Cand cnd{acc / (st.size[c.s] * st.size[sp]), st.id[c.s], st.id[sp], c.s, sp};
-            if (better(cnd, old)) st.rbest[c.s] = cnd;
+            if (better(cnd, old)) { st.rbest[c.s] = cnd; st.rb_l[c.s] = cnd.l; }
         }
     } else st.S[(uint64_t)sp * st.n + c.s] = acc;
 }
 
 }  // namespace
 
-// Wide: R[x][sp] += R[x][sq] (the merged cluster's approximate row sums), and every chain's number of work items.
-__global__ __launch_bounds__(256) void upgma_count_kernel(UpgmaState st)
+// The predicted running sum at every segment start of a segmented chain, from the row sums in R (one wavefront).  R's update
+// for the latest merge is applied by the NEXT select launch, so the new cluster's column is read as the sum of its two halves.
+__device__ void predict_chain(const UpgmaState &st, const Chain &c, uint32_t sp, uint32_t lane, SegRes *res)
 {
-    const uint32_t sp = *st.last_sp;
-    if (sp == 0xFFFFFFFFu || *st.done != 0) return;
-    const uint32_t sq = *st.last_sq, n = st.n, t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) {
-        float *r = st.R + (uint64_t)t * n;
-        r[sp] = r[sp] + r[sq];
-    }
-    if (t < 2u * *st.n_live) { const Chain c = get_chain(st, t, sp); st.item_count[t] = c.lane_chain ? 0u : c.nseg; }   // singletons' chains: upgma_short_kernel
-    if (t == 0) *st.pack_used = 0;
-}
-
-// One workgroup: item_start[w] = first work item of chain w (exclusive scan of the chains' item counts).
-__global__ __launch_bounds__(1024) void upgma_plan_kernel(UpgmaState st)
-{
-    __shared__ uint32_t part[1024];
-    const uint32_t sp = *st.last_sp;
-    if (sp == 0xFFFFFFFFu || *st.done != 0) { if (threadIdx.x == 0) *st.n_items = 0; return; }
-    const uint32_t chains = 2u * *st.n_live;
-    const uint32_t per = (chains + blockDim.x - 1) / blockDim.x, w0 = threadIdx.x * per, w1 = min(w0 + per, chains);
-    uint32_t sum = 0;
-    for (uint32_t w = w0; w < w1; ++w) sum += st.item_count[w];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (uint32_t o = 1; o < blockDim.x; o <<= 1) {                      // inclusive scan of the per-thread totals
-        const uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
-    for (uint32_t w = w0; w < w1; ++w) { st.item_start[w] = run; run += st.item_count[w]; }
-    if (threadIdx.x == blockDim.x - 1) { st.item_start[chains] = part[threadIdx.x]; *st.n_items = part[threadIdx.x]; }
-}
-
-// One wavefront per segmented chain: the predicted running sum at every segment start, from the row sums in R.
-__global__ __launch_bounds__(256) void upgma_predict_kernel(UpgmaState st)
-{
-    const uint32_t sp = *st.last_sp;
-    if (sp == 0xFFFFFFFFu || *st.done != 0) return;
-    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (w >= 2u * *st.n_live) return;
-    const Chain c = get_chain(st, w, sp);
-    if (c.nseg < 2) return;
-    SegRes *res = st.seg + st.item_start[w];
+    const bool fresh = c.slot_y == sp;
+    const uint32_t sq = *st.last_sq;
     float base = 0.0f;
     for (uint32_t a0 = 0; a0 < c.cx; a0 += 64) {
         const uint32_t a = a0 + lane;
-        const float v = a < c.cx ? st.R[(uint64_t)c.lx[a] * st.n + c.slot_y] : 0.0f;
+        float v = 0.0f;
+        if (a < c.cx) {
+            const float *r = st.R + (uint64_t)c.lx[a] * st.n;
+            v = fresh ? r[sp] + r[sq] : r[c.slot_y];
+        }
         float incl = v;                                                  // inclusive scan over the lanes (any rounding will do)
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(incl, o); if ((int)lane >= o) incl += t; }
@@ -632,111 +712,96 @@ __global__ __launch_bounds__(256) void upgma_predict_kernel(UpgmaState st)
     }
 }
 
-// A singleton against the new cluster (most chains of a merge, |Ck| terms each): ONE LANE per chain runs linkage()'s loop
-// literally -- one f32 accumulator, members of the new cluster ascending -- so nothing about the order needs proving.  The
-// 64 lanes of a wavefront hold 64 neighbouring singletons in one direction.  In both directions the matrix ROW of element i
-// is member i of the NEW cluster (a row of d for S[sp][s], a row of the transposed copy for S[s][sp]) and the column is the
-// singleton: the row sequence is wave-uniform (the member list goes through scalar loads), every load instruction reads
-// neighbouring floats of one row -- whole cache lines instead of one line per float -- and 32 loads are in flight per lane.
-__global__ __launch_bounds__(256) void upgma_short_kernel(UpgmaState st)
+// Launch 2 of a merge: every chain of the new cluster's row and column.
+//  * wavefronts [0, 2 ceil(n / 64)): SINGLETONS against the new cluster (most chains of a merge, |Ck| terms each): ONE LANE per
+//    chain runs linkage()'s loop literally -- one f32 accumulator, members of the new cluster ascending -- so nothing about the
+//    order needs proving.  The 64 lanes of a wavefront hold 64 neighbouring singletons in one direction.  In both directions the
+//    matrix ROW of element i is member i of the NEW cluster (a row of d for S[sp][s], a row of the transposed copy for S[s][sp])
+//    and the column is the singleton: the row sequence is wave-uniform (the member list goes through scalar loads), every load
+//    instruction reads neighbouring floats of one row -- whole cache lines instead of one line per float -- and 32 loads are in
+//    flight per lane.
+//  * wavefronts behind them, one per chain w: a chain of up to kShortChain elements is walked whole (exact::ordered_walk) and
+//    finished; a longer one reserves its nseg work items with one atomic add (their order among chains is irrelevant), records
+//    which chain they belong to, and writes the predicted sums the segment launch needs.
+__global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
 {
     const uint32_t sp = *st.last_sp;
     if (sp == 0xFFFFFFFFu || *st.done != 0) return;
     const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    const uint32_t nl = *st.n_live, dir = wid & 1u, cidx = (wid >> 1) * 64u + lane;
-    if ((wid >> 1) * 64u >= nl) return;
-    Chain c{};
-    if (cidx < nl) c = get_chain(st, 2u * cidx + dir, sp);
-    const bool active = c.lane_chain;
-    if (__ballot(active) == 0ull) return;
-    // element i is M[ck[i] * rs + own * cs]
-    const uint32_t K = st.mcount[sp];
-    const uint32_t *ck = st.pool + st.mstart[sp];                       // wave-uniform
-    const bool transposed = dir == 1 && st.dT != nullptr;
-    const float *M = transposed ? st.dT : st.d;
-    const uint64_t rs = (dir == 1 && !transposed) ? 1 : st.n, cs = (dir == 1 && !transposed) ? st.n : 1;
-    const uint64_t col = active ? (uint64_t)(dir ? c.lx[0] : c.ly[0]) * cs : 0;
-    float s = 0.0f;                                                      // distance = 0.0 (clustering.rs:154)
-    constexpr int kAhead = 32;
-    for (uint32_t i0 = 0; i0 < K; i0 += kAhead) {
-        float x[kAhead];
+    const uint32_t nl = *st.n_live;
+    const uint32_t group_waves = 2u * ((st.n + 63u) / 64u);
+    auto stamp = [&]() __attribute__((always_inline)) {                  // tuning aid: when the last wavefront with work finished
+        if (st.dbg && lane == 0) atomicMax(st.dbg + (uint64_t)(*st.n_ops - 1u) * 10 + 7, (unsigned long long)wall_clock64());
+    };
+    if (wid < group_waves) {
+        const uint32_t dir = wid & 1u, cidx = (wid >> 1) * 64u + lane;
+        if ((wid >> 1) * 64u >= nl) return;
+        // A singleton's slot holds the instance of the same number (slots are instance ids until they merge), so its chain needs no
+        // member-list lookups: live[cidx] -> mcount -> the loads.  (get_chain is only consulted for the record finish_chain wants.)
+        const uint32_t K = st.mcount[sp], ms = st.mstart[sp];
+        const uint32_t own = cidx < nl ? st.live[cidx] : sp;
+        const bool active = own != sp && K <= kLaneChain && st.mcount[own] == 1u;
+        if (__ballot(active) == 0ull) return;
+        // element i is M[ck[i] * rs + own * cs]
+        const uint32_t *ck = st.pool + ms;                              // wave-uniform
+        const bool transposed = dir == 1 && st.dT != nullptr;
+        const float *M = transposed ? st.dT : st.d;
+        const uint64_t rs = (dir == 1 && !transposed) ? 1 : st.n, cs = (dir == 1 && !transposed) ? st.n : 1;
+        const uint64_t col = active ? (uint64_t)own * cs : 0;
+        float s = 0.0f;                                                  // distance = 0.0 (clustering.rs:154)
+        constexpr int kAhead = 32;
+        for (uint32_t i0 = 0; i0 < K; i0 += kAhead) {
+            float x[kAhead];
 #pragma unroll
-        for (int u = 0; u < kAhead; ++u) {
-            const uint32_t r = ck[min(i0 + u, K - 1)];                  // uniform address: a scalar load
-            x[u] = M[(uint64_t)r * rs + col];
-        }
-#pragma unroll
-        for (int u = 0; u < kAhead; ++u) if (i0 + u < K) s = s + x[u];   // distance += d[x][y] (:162), in order
-    }
-    if (active) finish_chain(st, c, sp, s);
-}
-
-// Work items: a short chain is walked whole and finished; a segment of a long chain gets its integer map under the
-// predicted exponent.  Items are dealt to wavefronts in groups of 32 consecutive items per XCD (blocks b and b + 8 share an
-// XCD and its L2): the chains of neighbouring clusters read neighbouring floats of the same cache lines, so a line comes
-// in from HBM / Infinity Cache once per group instead of once per XCD.  (Placement is a speed matter only.)
-// A segment is also copied to `packed`, contiguously, when the commit pass is likely to re-walk it: the predicted sum
-// changes binade inside it or sits within 2^-10 of a power of two.
-__global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
-{
-    const uint32_t sp = *st.last_sp;
-    if (sp == 0xFFFFFFFFu || *st.done != 0) return;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t n_items = *st.n_items, chains = 2u * *st.n_live;
-    const uint32_t xcd = blockIdx.x & 7u, v = (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6);   // v-th wavefront of this XCD
-    const uint32_t groups_per_round = (gridDim.x >> 3) * 4u / 32u * 8u;                        // gridDim.x is a multiple of 64
-    for (uint32_t g = (v >> 5) * 8u + xcd; (uint64_t)g * 32u < n_items; g += groups_per_round) {
-        const uint32_t item = g * 32u + (v & 31u);
-        if (item >= n_items) break;
-        uint32_t lo = 0, hi = chains;                                    // chain of this item: largest w with item_start[w] <= item
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (st.item_start[mid] <= item) lo = mid; else hi = mid; }
-        const uint32_t w = lo;
-        const Chain c = get_chain(st, w, sp);
-        const exact::GatherSrc src = chain_src(st, c);
-        if (c.nseg == 1) {
-            const float acc = exact::ordered_walk<8>(src, lane, 0, (uint64_t)c.cx * c.cy, 0.0f);
-            if (lane == 0) finish_chain(st, c, sp, acc);
-            continue;
-        }
-        const uint32_t j = item - st.item_start[w];
-        SegRes *res = st.seg + item;
-        const uint32_t pb = __builtin_bit_cast(uint32_t, res->predicted), es = pb >> 23;
-        exact::Fn f{exact::kCap, exact::kCap};
-        uint32_t pack_off = 0xFFFFFFFFu;
-        if (es >= 1u && es <= 254u) {
-            const uint64_t begin = (uint64_t)j * c.rps * c.cy, end = min<uint64_t>(begin + (uint64_t)c.rps * c.cy, (uint64_t)c.cx * c.cy);
-            const uint32_t len = (uint32_t)(end - begin);
-            // will the commit pass re-walk this segment?  (the next segment's prediction is this segment's predicted end)
-            const uint32_t nb = j + 1 < c.nseg ? __builtin_bit_cast(uint32_t, res[1].predicted) : 0xFFFFFFFFu;
-            const uint32_t frac = pb & 0x7FFFFFu, nfrac = nb & 0x7FFFFFu;
-            const bool risky = (nb >> 23) != es || frac < (1u << 13) || nfrac > 0x7FFFFFu - (1u << 13);
-            if (risky && st.packed) {
-                if (lane == 0) {
-                    pack_off = atomicAdd(st.pack_used, len);
-                    if ((uint64_t)pack_off + len > st.pack_capacity) pack_off = 0xFFFFFFFFu;
-                }
-                pack_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)pack_off);
+            for (int u = 0; u < kAhead; ++u) {
+                const uint32_t r = ck[min(i0 + u, K - 1)];              // uniform address: a scalar load
+                x[u] = M[(uint64_t)r * rs + col];
             }
-            f = exact::segment_fn(src, lane, begin, end, es, pack_off != 0xFFFFFFFFu ? st.packed + pack_off : nullptr);
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) if (i0 + u < K) s = s + x[u];   // distance += d[x][y] (:162), in order
         }
-        if (lane == 0) {
-            res->es = (f.a0 >= exact::kCap || f.a1 >= exact::kCap) ? 0u : es;
-            res->a0 = f.a0; res->a1 = f.a1;
-            res->pack = pack_off;
-        }
+        Chain c{};
+        c.s = own; c.dir = dir;
+        if (active) finish_chain(st, c, sp, s);
+        stamp();
+        return;
     }
+    // wavefronts [0, 2 n_big): the chains against the clusters of two or more members; behind them, only when the NEW cluster is too
+    // large for one lane per singleton (more than kLaneChain members), one wavefront per chain against a singleton
+    const uint32_t v = wid - group_waves, nb2 = 2u * *st.n_big;
+    uint32_t w;
+    if (v < nb2) w = 2u * st.pos[st.big[v >> 1]] + (v & 1u);
+    else {
+        if (st.mcount[sp] <= kLaneChain || v - nb2 >= 2u * nl) return;
+        w = v - nb2;
+        if (st.mcount[st.live[w >> 1]] != 1u) return;                    // covered by the first range
+    }
+    const Chain c = get_chain(st, w, sp);
+    if (c.nseg == 0 || c.lane_chain) return;
+    if (c.nseg == 1) {
+        const float acc = exact::ordered_walk<8>(chain_src(st, c), lane, 0, (uint64_t)c.cx * c.cy, 0.0f);
+        if (lane == 0) finish_chain(st, c, sp, acc);
+        stamp();
+        return;
+    }
+    uint32_t base = 0;
+    if (lane == 0) { base = atomicAdd(st.n_items, c.nseg); st.item_start[w] = base; st.seg_done[w] = 0u; }
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    for (uint32_t j = lane; j < c.nseg; j += 64) st.item_chain[base + j] = w;
+    predict_chain(st, c, sp, lane, st.seg + base);
+    stamp();
 }
 
-// One wavefront per segmented chain: the true sum through the segments, in order.
-__global__ __launch_bounds__(256) void upgma_commit_kernel(UpgmaState st)
+// Launch 3 of a merge: the segments of the long chains.  A segment gets its integer map under the predicted exponent
+// (exact::segment_fn).  Items are dealt to wavefronts in groups of 32 consecutive items per XCD (blocks b and b + 8 share an XCD
+// and its L2): neighbouring segments read neighbouring rows, so a line comes in from HBM / Infinity Cache once per group instead
+// of once per XCD.  (Placement is a speed matter only.)  A segment is also copied to `packed`, contiguously, when the commit is
+// likely to re-walk it: the predicted sum changes binade inside it or sits within 2^-10 of a power of two.
+// The wavefront that finishes the LAST segment of a chain (atomic counter behind a fence) commits the chain: the true sum through
+// the segments, in order -- a segment whose assumed exponent matches and whose map keeps the sum inside the binade is applied in
+// O(1), any other one is re-walked element by element from the true sum.
+__device__ void commit_chain(const UpgmaState &st, const Chain &c, uint32_t sp, uint32_t lane, const SegRes *res)
 {
-    const uint32_t sp = *st.last_sp;
-    if (sp == 0xFFFFFFFFu || *st.done != 0) return;
-    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (w >= 2u * *st.n_live) return;
-    const Chain c = get_chain(st, w, sp);
-    if (c.nseg < 2) return;
-    const SegRes *res = st.seg + st.item_start[w];
     const uint64_t total = (uint64_t)c.cx * c.cy, seg_len = (uint64_t)c.rps * c.cy;
     float s = 0.0f;
     for (uint32_t j0 = 0; j0 < c.nseg; j0 += 64) {
@@ -763,6 +828,58 @@ __global__ __launch_bounds__(256) void upgma_commit_kernel(UpgmaState st)
         }
     }
     if (lane == 0) finish_chain(st, c, sp, s);
+}
+
+__global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
+{
+    const uint32_t sp = *st.last_sp;
+    if (sp == 0xFFFFFFFFu || *st.done != 0) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n_items = *st.n_items;
+    const uint32_t xcd = blockIdx.x & 7u, v = (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6);   // v-th wavefront of this XCD
+    const uint32_t groups_per_round = (gridDim.x >> 3) * 4u / 32u * 8u;                        // gridDim.x is a multiple of 64
+    for (uint32_t g = (v >> 5) * 8u + xcd; (uint64_t)g * 32u < n_items; g += groups_per_round) {
+        const uint32_t item = g * 32u + (v & 31u);
+        if (item >= n_items) break;
+        const uint32_t w = st.item_chain[item];
+        const Chain c = get_chain(st, w, sp);
+        const exact::GatherSrc src = chain_src(st, c);
+        const uint32_t first = st.item_start[w], j = item - first;
+        SegRes *res = st.seg + item;
+        const uint32_t pb = __builtin_bit_cast(uint32_t, res->predicted), es = pb >> 23;
+        exact::Fn f{exact::kCap, exact::kCap};
+        uint32_t pack_off = 0xFFFFFFFFu;
+        if (es >= 1u && es <= 254u) {
+            const uint64_t begin = (uint64_t)j * c.rps * c.cy, end = min<uint64_t>(begin + (uint64_t)c.rps * c.cy, (uint64_t)c.cx * c.cy);
+            const uint32_t len = (uint32_t)(end - begin);
+            // will the commit re-walk this segment?  (the next segment's prediction is this segment's predicted end)
+            const uint32_t nb = j + 1 < c.nseg ? __builtin_bit_cast(uint32_t, res[1].predicted) : 0xFFFFFFFFu;
+            const uint32_t frac = pb & 0x7FFFFFu, nfrac = nb & 0x7FFFFFu;
+            const bool risky = (nb >> 23) != es || frac < (1u << 13) || nfrac > 0x7FFFFFu - (1u << 13);
+            if (risky && st.packed) {
+                if (lane == 0) {
+                    pack_off = atomicAdd(st.pack_used, len);
+                    if ((uint64_t)pack_off + len > st.pack_capacity) pack_off = 0xFFFFFFFFu;
+                }
+                pack_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)pack_off);
+            }
+            f = exact::segment_fn(src, lane, begin, end, es, pack_off != 0xFFFFFFFFu ? st.packed + pack_off : nullptr);
+        }
+        uint32_t finished = 0;
+        if (lane == 0) {
+            res->es = (f.a0 >= exact::kCap || f.a1 >= exact::kCap) ? 0u : es;
+            res->a0 = f.a0; res->a1 = f.a1;
+            res->pack = pack_off;
+        }
+        __threadfence();                                                 // this segment's map and packed copy (every lane's stores) first ...
+        if (lane == 0) finished = atomicAdd(&st.seg_done[w], 1u) + 1u;   // ... then the count
+        finished = (uint32_t)__builtin_amdgcn_readfirstlane((int)finished);
+        if (finished == c.nseg) {
+            __threadfence();                                             // acquire: the other wavefronts' results, not a stale L1 line
+            commit_chain(st, c, sp, lane, st.seg + first);
+        }
+        if (st.dbg && lane == 0) atomicMax(st.dbg + (uint64_t)(*st.n_ops - 1u) * 10 + 8, (unsigned long long)wall_clock64());
+    }
 }
 
 __global__ void upgma_init_S_kernel(UpgmaState st)
@@ -799,9 +916,14 @@ __global__ __launch_bounds__(256) void upgma_transpose_kernel(const float *__res
 __global__ void upgma_init_kernel(UpgmaState st)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < st.n) { st.size[i] = 1.0f; st.id[i] = i; st.live[i] = i; st.pool[i] = i; st.mstart[i] = i; st.mcount[i] = 1; st.rscan[i] = 1; }   // parents = [0..n) (:88-91)
+    if (i < st.n) {                                                       // parents = [0..n) (:88-91); every row minimum is still to be found
+        st.size[i] = 1.0f; st.id[i] = i; st.live[i] = i; st.pos[i] = i; st.pool[i] = i; st.mstart[i] = i; st.mcount[i] = 1;
+        st.rscan[i] = 1; st.stale[i] = i; st.rb_l[i] = __builtin_inff(); st.bpos[i] = 0xFFFFFFFFu;
+    }
     if (i == 0) {
         *st.n_live = st.n;
+        *st.n_big = 0;
+        *st.n_stale = st.n; *st.arrive = 0; *st.r_pending = 0; *st.n_items = 0; *st.pack_used = 0; *st.last_sq = 0;
         *st.n_ops = 0;
         *st.pool_used = st.n;
         *st.last_sp = 0xFFFFFFFFu;
@@ -842,7 +964,6 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
 
     UpgmaState st{};
     st.n = n;
-    const int n_blocks = (int)std::min<uint32_t>(n, 4096);
     char *pool = nullptr;
     const size_t bytes_S = nn * sizeof(float), bytes_f = (size_t)n * sizeof(float), bytes_u = (size_t)n * sizeof(uint32_t);
     const size_t bytes_lists = ((size_t)n * (n + 1) / 2 + n) * sizeof(uint32_t);    // every merged list is appended once
@@ -850,39 +971,49 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     // segments of one merge: sum over chains of ceil(rows / rows-per-segment) <= 2 (sum of chain lengths) / kSegElems + chains,
     // and the chains of one merge hold 2 |Ck| (n - |Ck|) <= n^2 / 2 elements
     const size_t max_items = (size_t)(nn / kSegElems) + 2 * (size_t)n + 64;
-    const size_t bytes_items = (2 * (size_t)n + 2) * sizeof(uint32_t), bytes_seg = max_items * sizeof(SegRes);
+    const size_t bytes_items = (2 * (size_t)n + 2) * sizeof(uint32_t), bytes_seg = max_items * sizeof(SegRes), bytes_ichain = max_items * sizeof(uint32_t);
     // packed copies of the segments the commit pass is likely to re-walk (a few per chain); when it is full, they are gathered again
     const size_t bytes_packed = (size_t)std::min<uint64_t>(nn / 8 + 65536, 1ull << 30) * sizeof(float);
-    const size_t total = 3 * bytes_S + bytes_d + bytes_lists + bytes_f + 5 * bytes_u + (size_t)n * sizeof(Cand) +
-                         (size_t)n * sizeof(apd_cluster_op) + 2 * bytes_items + bytes_seg + bytes_packed + 1024;
-    HIP_TRY(ctx, hipMalloc((void **)&pool, total));
+    // one allocation, every array on a 256-byte boundary (the row scans read S rows, sizes and ids with 16-byte loads)
     size_t off = 0;
-    st.S = (float *)(pool + off); off += bytes_S;
-    st.R = (float *)(pool + off); off += bytes_S;
-    float *d_copy = (float *)(pool + off); off += bytes_d;
-    st.pool = (uint32_t *)(pool + off); off += bytes_lists;
-    st.size = (float *)(pool + off); off += bytes_f;
-    st.id = (uint32_t *)(pool + off); off += bytes_u;
-    st.live = (uint32_t *)(pool + off); off += bytes_u;
-    st.mstart = (uint32_t *)(pool + off); off += bytes_u;
-    st.mcount = (uint32_t *)(pool + off); off += bytes_u;
-    st.rscan = (uint32_t *)(pool + off); off += bytes_u;
-    st.rbest = (Cand *)(pool + off); off += (size_t)n * sizeof(Cand);
-    st.ops = (apd_cluster_op *)(pool + off); off += (size_t)n * sizeof(apd_cluster_op);
-    off = (off + 63) & ~(size_t)63;
-    st.seg = (SegRes *)(pool + off); off += bytes_seg;
-    st.item_start = (uint32_t *)(pool + off); off += bytes_items;
-    st.item_count = (uint32_t *)(pool + off); off += bytes_items;
-    off = (off + 255) & ~(size_t)255;
-    st.packed = (float *)(pool + off); off += bytes_packed;
+    auto carve = [&](size_t bytes) { off = (off + 255) & ~(size_t)255; const size_t at = off; off += bytes; return at; };
+    const size_t o_S = carve(bytes_S), o_R = carve(bytes_S), o_d = carve(bytes_d), o_lists = carve(bytes_lists), o_size = carve(bytes_f),
+                 o_id = carve(bytes_u), o_live = carve(bytes_u), o_mstart = carve(bytes_u), o_mcount = carve(bytes_u), o_rscan = carve(bytes_u),
+                 o_pos = carve(bytes_u), o_big = carve(bytes_u), o_bpos = carve(bytes_u), o_rbl = carve(bytes_f), o_stale = carve(bytes_u),
+                 o_rbest = carve((size_t)n * sizeof(Cand)), o_ops = carve((size_t)n * sizeof(apd_cluster_op)), o_seg = carve(bytes_seg),
+                 o_istart = carve(bytes_items), o_sdone = carve(bytes_items), o_ichain = carve(bytes_ichain), o_packed = carve(bytes_packed),
+                 o_T = carve(bytes_S), o_words = carve(256);
+    HIP_TRY(ctx, hipMalloc((void **)&pool, off));
+    st.S = (float *)(pool + o_S);
+    st.R = (float *)(pool + o_R);
+    float *d_copy = (float *)(pool + o_d);
+    st.pool = (uint32_t *)(pool + o_lists);
+    st.size = (float *)(pool + o_size);
+    st.id = (uint32_t *)(pool + o_id);
+    st.live = (uint32_t *)(pool + o_live);
+    st.mstart = (uint32_t *)(pool + o_mstart);
+    st.mcount = (uint32_t *)(pool + o_mcount);
+    st.rscan = (uint32_t *)(pool + o_rscan);
+    st.pos = (uint32_t *)(pool + o_pos);
+    st.big = (uint32_t *)(pool + o_big);
+    st.bpos = (uint32_t *)(pool + o_bpos);
+    st.rb_l = (float *)(pool + o_rbl);
+    st.stale = (uint32_t *)(pool + o_stale);
+    st.rbest = (Cand *)(pool + o_rbest);
+    st.ops = (apd_cluster_op *)(pool + o_ops);
+    st.seg = (SegRes *)(pool + o_seg);
+    st.item_start = (uint32_t *)(pool + o_istart);
+    st.seg_done = (uint32_t *)(pool + o_sdone);
+    st.item_chain = (uint32_t *)(pool + o_ichain);
+    st.packed = (float *)(pool + o_packed);
     st.pack_capacity = (uint32_t)(bytes_packed / sizeof(float));
-    float *d_T = (float *)(pool + off); off += bytes_S;
+    float *d_T = (float *)(pool + o_T);
     st.dT = d_T;
-    off = (off + 63) & ~(size_t)63;
-    st.n_live = (uint32_t *)(pool + off); st.n_ops = st.n_live + 1; st.done = st.n_live + 2;
+    st.n_live = (uint32_t *)(pool + o_words); st.n_ops = st.n_live + 1; st.done = st.n_live + 2;     // host_state reads these three
     st.pool_used = st.n_live + 3; st.last_sp = st.n_live + 4; st.last_sq = st.n_live + 5; st.n_items = st.n_live + 6;
-    st.pack_used = st.n_live + 7;
-    auto fail = [&](int rc) { hipFree(pool); return rc; };
+    st.pack_used = st.n_live + 7; st.n_stale = st.n_live + 8; st.arrive = st.n_live + 9; st.r_pending = st.n_live + 10;
+    st.n_big = st.n_live + 11;
+    auto fail = [&](int rc) { hipFree(pool); if (st.dbg) hipFree(st.dbg); return rc; };
     if (distances_on_device) st.d = distances;
     else {
         hipError_t e0 = hipMemcpyAsync(d_copy, distances, bytes_S, hipMemcpyHostToDevice, ctx->stream);
@@ -902,24 +1033,25 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     hipLaunchKernelGGL(upgma_transpose_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)((n + 31) / 32) * ((n + 31) / 32), 16384)), dim3(256), 0,
                        ctx->stream, st.d, d_T, n);
     uint32_t host_state[3] = {n, 0, 0};                                   // n_live, n_ops, done
-    // The merge loop is launch-bound (six short dependent launches per merge): a batch of merges is captured once into a
+    // The merge loop is launch-bound (three short dependent launches per merge): a batch of merges is captured once into a
     // hipGraph and replayed until the device-side `done` flag rises; kernels launched after that return immediately.
     const uint32_t batch = 64;
-    const uint32_t chain_blocks = (2 * n + 3) / 4;                        // one wavefront per (other cluster, direction)
-    const uint32_t segment_blocks = (std::min(chain_blocks, 8192u) + 63u) / 64u * 64u;   // groups of 32 wavefronts per XCD
-    const uint32_t short_blocks = (2 * ((n + 63) / 64) + 3) / 4;         // one wavefront per (64 clusters, direction)
+    // stale rows per merge: a handful (the first launch loops over all n); every workgroup costs an arrival, 8 .. 64 measured alike
+    const uint32_t select_blocks = std::min<uint32_t>(std::max<uint32_t>(n / 128u, 1u), 64u);
+    const uint32_t chain_waves = 2 * ((n + 63) / 64) + 2 * n;             // singleton groups, then one wavefront per (other cluster, direction)
+    const uint32_t chain_blocks = (chain_waves + 3) / 4;
+    // one wavefront per item up to 32768 items (a wavefront that commits a chain must not hold other items back), grid-stride beyond
+    const uint32_t segment_blocks = (std::min((2 * n + 3) / 4, 8192u) + 63u) / 64u * 64u;   // groups of 32 wavefronts per XCD
+    const bool debug_timing = std::getenv("APD_DEBUG_UPGMA_TIMING") != nullptr;   // tuning aid: phase stamps of every select launch
+    if (debug_timing && hipMalloc((void **)&st.dbg, (size_t)n * 10 * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemsetAsync(st.dbg, 0, (size_t)n * 10 * sizeof(unsigned long long), ctx->stream);
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     auto enqueue_batch = [&]() {
         for (uint32_t b = 0; b < batch; ++b) {
-            hipLaunchKernelGGL(upgma_rowmin_kernel, dim3(n_blocks), dim3(1024), 0, ctx->stream, st);
-            hipLaunchKernelGGL(upgma_merge_kernel, dim3(1), dim3(1024), 0, ctx->stream, st);
-            hipLaunchKernelGGL(upgma_count_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, ctx->stream, st);
-            hipLaunchKernelGGL(upgma_plan_kernel, dim3(1), dim3(1024), 0, ctx->stream, st);
-            hipLaunchKernelGGL(upgma_short_kernel, dim3(short_blocks), dim3(256), 0, ctx->stream, st);
-            hipLaunchKernelGGL(upgma_predict_kernel, dim3(chain_blocks), dim3(256), 0, ctx->stream, st);
+            hipLaunchKernelGGL(upgma_select_kernel, dim3(select_blocks), dim3(1024), 0, ctx->stream, st);
+            hipLaunchKernelGGL(upgma_chain_kernel, dim3(chain_blocks), dim3(256), 0, ctx->stream, st);
             hipLaunchKernelGGL(upgma_segment_kernel, dim3(segment_blocks), dim3(256), 0, ctx->stream, st);
-            hipLaunchKernelGGL(upgma_commit_kernel, dim3(chain_blocks), dim3(256), 0, ctx->stream, st);
         }
     };
     auto drop_graph = [&]() { if (exec) hipGraphExecDestroy(exec); if (graph) hipGraphDestroy(graph); exec = nullptr; graph = nullptr; };
@@ -934,6 +1066,7 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     }
     (void)hipGetLastError();
     const bool debug = std::getenv("APD_DEBUG_UPGMA") != nullptr;
+
     uint32_t ops_before = 0;
     while (true) {
         if (use_graph) e = hipGraphLaunch(exec, ctx->stream);
@@ -953,6 +1086,25 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     }
     drop_graph();
     const uint32_t cnt = host_state[1];
+    if (st.dbg) {
+        std::vector<unsigned long long> g((size_t)n * 10);
+        if (hipMemcpy(g.data(), st.dbg, g.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess && cnt > 1) {
+            double ph[4] = {0, 0, 0, 0}, stale = 0, merged = 0, chain = 0, seg = 0, gap = 0;
+            for (uint32_t t = 1; t + 1 < cnt; ++t) {                      // stamps: 100 MHz; merge 0 scans every row, the last merge ends the loop
+                const unsigned long long *q = &g[(size_t)t * 10];
+                for (int k = 0; k < 4; ++k) ph[k] += (double)(q[k + 1] - q[k]) * 0.01;
+                stale += (double)q[5]; merged += (double)q[6];
+                chain += (double)(q[7] - q[4]) * 0.01;                    // end of select's bookkeeping -> last wavefront of the chain launch
+                seg += (double)(std::max(q[8], q[7]) - q[7]) * 0.01;      // -> last wavefront of the segment launch that had work
+                gap += (double)(g[(size_t)(t + 1) * 10] - std::max(q[8], q[7])) * 0.01;
+            }
+            const double m = std::max(1.0, (double)cnt - 2.0);
+            std::fprintf(stderr, "[apd] upgma us per merge: select [rows %.2f | arrive %.2f | argmin %.2f | lists %.2f] chain launch %.2f, segment launch %.2f, "
+                                 "to the next select's entry %.2f ; stale rows %.1f, merged list %.1f members\n",
+                         ph[0] / m, ph[1] / m, ph[2] / m, ph[3] / m, chain / m, seg / m, gap / m, stale / m, merged / m);
+        }
+        hipFree(st.dbg);
+    }
     std::vector<uint32_t> ids(n), live(host_state[0]);
     e = hipMemcpyAsync(ops, st.ops, (size_t)cnt * sizeof(apd_cluster_op), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(ids.data(), st.id, bytes_u, hipMemcpyDeviceToHost, ctx->stream);

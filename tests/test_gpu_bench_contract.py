@@ -50,9 +50,17 @@ def test_bench_secondary_workloads_and_in_process_multi_device():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["config"]["workload"].startswith("cfg2") and d["parity_census"]["over_1e-4"] == 0
-    for name in ("cfg2", "cfg1"):
+    for name in ("cfg2", "cfg1", "cfg4", "cfg5s"):
         s = d["secondary"][name]
         assert s["workload"].startswith(name) and s["kernel_ms"] > 0 and 0 < s["roofline_frac"] < 1 and s["parity_ok"] is True
+    for name in ("cfg4", "cfg5s"):                                    # the driver-visible BASELINE shapes beyond cfg3: own census, own strict pass
+        s = d["secondary"][name]
+        pc = s["parity_census"]
+        assert pc["entries"] == (4096 if name == "cfg4" else 512) ** 2 and pc["nonfinite_pattern_equal"] and pc["zero_pattern_equal"]
+        # the default form's one known deviation: a handful of entries at most, each below 3e-3
+        assert pc["over_1e-4"] <= 8 and pc["max_rel"] <= 3e-3, pc
+        assert s["strict"]["kernel_ms"] > s["kernel_ms"] and s["strict"]["bitwise_equal_to_oracle_sample"] == "32 of 32"
+    assert "cfg3_strict" not in d["secondary"]                        # only next to the cfg3 headline (it reuses that run's census pass)
     # the same shape measured twice in one run agrees with itself
     assert abs(d["secondary"]["cfg2"]["kernel_ms"] / d["roofline"]["kernel_ms"] - 1.0) < 0.15
 
@@ -64,10 +72,15 @@ def test_bench_gpus_2_in_process_rehearsal_on_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env.update(APD_MULTI_COLLECTIVE="peer", APD_BENCH_DEVICES="0,0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg1", "--steps", "2", "--warmup", "1",
-                          "--cpu-seconds", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+                          "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["ranks_seen"] == 2
+    # N > 1 lines: the run verified itself before timing (same batch on N devices and on device 0 alone), the CPU baseline is
+    # there for every N, and the recorded single-GPU counters are withheld with the reason
+    assert d["config"]["multi_selfcheck"] == "bitwise"
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert d["roofline"]["traffic"] is None and d["roofline"]["traffic_withheld"]
     assert d["config"]["launch"].startswith("one process driving 2 devices") and d["config"]["torch_imported"] is False
     assert d["config"]["collective_fallback"] is True and "peer-copy" in d["config"]["collective_error"]
     assert d["parity_ok"] is True and d["parity_census"]["over_1e-4"] == 0
