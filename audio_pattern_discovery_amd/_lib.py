@@ -143,6 +143,14 @@ SYMBOLS = [
                                  _u32p, _f32p]),
     ("apd_cluster_sets", C.c_int, [C.POINTER(ClusterOp), C.c_uint32, _u32p, C.c_uint32, C.c_uint32, _u32p, _u32p,
                                    _u32p]),
+    ("apd_encoder_create", C.c_int, [_vp, _f32p, _f32p, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
+    ("apd_encoder_destroy", C.c_int, [_vp]),
+    ("apd_encode_async", C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp]),
+    ("apd_cepstrum_plan_create", C.c_int, [_vp, _u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _u64p, _u32p, C.POINTER(_vp)]),
+    ("apd_cepstrum_plan_destroy", C.c_int, [_vp]),
+    ("apd_cepstrum_batch_async", C.c_int, [_vp, _vp, _vp, _vp]),
+    ("apd_stream_busy", C.c_int, [_vp, C.POINTER(C.c_int)]),
+    ("apd_debug_affinity_probe", C.c_int, [_vp, _vp, C.POINTER(C.c_int)]),
     ("apd_encode", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, _f32p, _f32p, C.c_uint32, C.c_int, _vp]),
     ("apd_interesting_ranges", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64, C.c_int, _u64p,
                                          C.c_uint64, _u64p]),
@@ -256,6 +264,12 @@ class Context:
         bad, first, hist = C.c_uint64(0), C.c_uint32(0), (C.c_uint64 * 5)()
         check(lib().apd_selftest_sqrt(self.handle, first_bits, count, C.byref(bad), C.byref(first), hist), self.handle)
         return bad.value, first.value, list(hist)
+
+    def stream_busy(self):
+        """TEST HOOK: True while work enqueued on the context's stream has not finished."""
+        b = C.c_int(0)
+        check(lib().apd_stream_busy(self.handle, C.byref(b)), self.handle)
+        return bool(b.value)
 
     def set_fault_injection(self, drop_tiles):
         """TEST HOOK: the next alignment launches skip the last `drop_tiles` tiles of every kernel class."""

@@ -25,6 +25,7 @@ namespace {
 
 int ensure_ws(apd_context *ctx, void **p, size_t *have, size_t need)
 {
+    APD_AFFINITY(ctx, "workspace allocation");
     if (*have >= need && *p) return APD_OK;
     if (*p) { HIP_TRY(ctx, hipFree(*p)); *p = nullptr; *have = 0; }
     HIP_TRY(ctx, hipMalloc(p, need));
@@ -70,6 +71,33 @@ uint64_t band_cells(uint64_t n, uint64_t m, uint64_t w)
 
 }  // namespace
 
+namespace apd {
+thread_local const apd_context *tl_bound_context = nullptr;
+bool affinity_debug()
+{
+    static const bool on = [] { const char *v = std::getenv("APD_DEBUG_AFFINITY"); return v && v[0] && v[0] != '0'; }();
+    return on;
+}
+hipError_t bind_device(const apd_context *ctx)
+{
+    tl_bound_context = ctx;
+    return hipSetDevice(ctx->device);
+}
+bool affinity_ok(const apd_context *ctx, const char *where)
+{
+    int dev = -1;
+    const bool ok = tl_bound_context == ctx && hipGetDevice(&dev) == hipSuccess && dev == ctx->device;
+    if (!ok) {
+        const_cast<apd_context *>(ctx)->last_error = std::string("APD_DEBUG_AFFINITY: ") + where + " on a thread bound to " +
+            (tl_bound_context == ctx ? "this context but HIP device " + std::to_string(dev) :
+             tl_bound_context ? "another context (device " + std::to_string(tl_bound_context->device) + ")" : "no context") +
+            ", expected device " + std::to_string(ctx->device);
+        std::fprintf(stderr, "[apd] %s\n", ctx->last_error.c_str());
+    }
+    return ok;
+}
+}  // namespace apd
+
 // ------------------------------------------------------------------------------------ context
 
 extern "C" const char *apd_status_string(int s)
@@ -102,7 +130,7 @@ extern "C" int apd_create(int device, apd_context **out)
     apd_context *ctx = new (std::nothrow) apd_context();
     if (!ctx) return APD_ERR_OOM;
     ctx->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (bind_device(ctx) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return APD_ERR_HIP;
     }
@@ -128,12 +156,16 @@ static void release_batch_device_memory(apd_batch *b);
 extern "C" int apd_destroy(apd_context *ctx)
 {
     if (!ctx) return APD_ERR_INVALID_ARG;
-    hipSetDevice(ctx->device);
+    bind_device(ctx);
     hipStreamSynchronize(ctx->stream);
     for (apd_batch *b : ctx->batches) { release_batch_device_memory(b); b->ctx = nullptr; }   // orphans: see apd_batch_destroy
     ctx->batches.clear();
     for (apd_comm *c : ctx->comms) apd::orphan_comm(c);
     ctx->comms.clear();
+    for (apd_encoder *e : ctx->encoders) apd::orphan_encoder(e);
+    ctx->encoders.clear();
+    for (apd_cepstrum_plan *cp : ctx->cepstrum_plans) apd::orphan_cepstrum_plan(cp);
+    ctx->cepstrum_plans.clear();
     for (void *p : ctx->buffers) hipFree(p);                              // apd_device_alloc'ed and never freed
     ctx->buffers.clear();
     if (ctx->ws_tiles) hipFree(ctx->ws_tiles);
@@ -179,8 +211,27 @@ static int sync_and_report(apd_context *ctx)
 extern "C" int apd_synchronize(apd_context *ctx)
 {
     if (!ctx) return APD_ERR_INVALID_ARG;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, bind_device(ctx));
     return sync_and_report(ctx);
+}
+
+extern "C" int apd_debug_affinity_probe(apd_context *bound, apd_context *checked, int *enabled)
+{
+    if (!bound || !checked) return APD_ERR_INVALID_ARG;
+    if (enabled) *enabled = apd::affinity_debug() ? 1 : 0;
+    HIP_TRY(bound, bind_device(bound));
+    APD_AFFINITY(checked, "affinity probe");                              // what every allocation / event / launch in the library does
+    return APD_OK;
+}
+
+extern "C" int apd_stream_busy(apd_context *ctx, int *busy)
+{
+    if (!ctx || !busy) return APD_ERR_INVALID_ARG;
+    HIP_TRY(ctx, bind_device(ctx));
+    const hipError_t e = hipStreamQuery(ctx->stream);
+    if (e != hipSuccess && e != hipErrorNotReady) { ctx->last_error = std::string("hipStreamQuery: ") + hipGetErrorString(e); return APD_ERR_HIP; }
+    *busy = e == hipErrorNotReady ? 1 : 0;
+    return APD_OK;
 }
 
 extern "C" int apd_set_fault_injection(apd_context *ctx, uint32_t drop_tiles)
@@ -227,7 +278,7 @@ extern "C" int apd_set_distance_mode(apd_context *ctx, int mode, float tau)
 extern "C" int apd_selftest(apd_context *ctx)
 {
     if (!ctx) return APD_ERR_INVALID_ARG;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, bind_device(ctx));
     int rc = ensure_ws(ctx, &ctx->ws_misc, &ctx->ws_misc_bytes, 256);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->ws_misc, 0, sizeof(int), ctx->stream));
@@ -243,7 +294,7 @@ extern "C" int apd_selftest_sqrt(apd_context *ctx, uint32_t first_bits, uint64_t
                                  uint64_t *raw_ulp_hist)
 {
     if (!ctx || !mismatches || count > (1ull << 32)) return APD_ERR_INVALID_ARG;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, bind_device(ctx));
     int rc = ensure_ws(ctx, &ctx->ws_misc, &ctx->ws_misc_bytes, 256);
     if (rc) return rc;
     unsigned long long h[7] = {0, ~0ull, 0, 0, 0, 0, 0};
@@ -282,7 +333,7 @@ extern "C" int apd_batch_create(apd_context *ctx, const float *frames, const uin
 {
     if (!ctx || !offsets || !out || dim == 0 || dim > 1024) return APD_ERR_INVALID_ARG;
     *out = nullptr;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, bind_device(ctx));
     const uint64_t total = offsets[n_seq];
     if (total > 0 && !frames) return APD_ERR_INVALID_ARG;
     if (total + 2ull * n_seq >= (1ull << 32) || offsets[0] != 0) return APD_ERR_INVALID_ARG;
@@ -334,7 +385,7 @@ extern "C" int apd_batch_refill(apd_context *ctx, apd_batch *b, const float *fra
     if (!ctx || !b || b->ctx != ctx) return APD_ERR_INVALID_ARG;
     const uint64_t total = b->total_frames, padded_frames = total + 2ull * b->n_seq;
     if (total > 0 && !frames) return APD_ERR_INVALID_ARG;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, bind_device(ctx));
     b->nonfinite = -1;
     HIP_TRY(ctx, hipMemsetAsync(b->d_flags, 0, (4 + (size_t)b->n_seq + 1) * sizeof(uint32_t), ctx->stream));   // flags and the per-sequence norm maxima
     if (padded_frames > 0) {
@@ -372,7 +423,7 @@ static int batch_nonfinite(apd_context *ctx, const apd_batch *b, bool *out)
 extern "C" int apd_batch_nonfinite(apd_context *ctx, const apd_batch *b, int *nonfinite)
 {
     if (!ctx || !b || !nonfinite || b->ctx != ctx) return APD_ERR_INVALID_ARG;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, bind_device(ctx));
     bool nf = false;
     const int rc = batch_nonfinite(ctx, b, &nf);
     *nonfinite = nf ? 1 : 0;
@@ -392,7 +443,7 @@ extern "C" int apd_batch_destroy(apd_batch *b)
 {
     if (!b) return APD_ERR_INVALID_ARG;
     if (b->ctx) {                                                        // else: orphaned by apd_destroy, device memory already released
-        hipSetDevice(b->ctx->device);
+        bind_device(b->ctx);
         hipStreamSynchronize(b->ctx->stream);
         release_batch_device_memory(b);
         b->ctx->batches.erase(b);
@@ -597,7 +648,7 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
     if (!ctx || !batch || !d_slab || world == 0 || rank >= world || batch->ctx != ctx) return APD_ERR_INVALID_ARG;
     int rc = check_lengths(batch);
     if (rc) return rc;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, bind_device(ctx));
     const bool pens_ok = (band.ins > 0.0f) && (band.del > 0.0f) && (band.mat > 0.0f) && (band.ins < INFINITY) &&
                          (band.del < INFINITY) && (band.mat < INFINITY);   // the systolic kernel needs pen * INF = INF
     // A NaN / infinite feature anywhere in the batch means: literal kernel only (the fast kernels' selects and sentinels assume
@@ -619,8 +670,10 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
         }
     }
     const bool fast_ok = static_fast && !nonfinite;
-    // strict mode: every tile takes the kernels built for unequal penalties -- literal comparison chain on distances computed
-    // operation for operation as numerics.rs:114-120 -- which are bit-identical to the CPU arithmetic for ANY penalties
+    // strict mode: distances computed operation for operation as numerics.rs:114-120 in every kernel family.  The band kernels
+    // keep the fast select with unit penalties (it picks the reference's predecessor for every non-NaN input: dtw_systolic.h, <.., true,
+    // false>) and take the literal comparison chain with any others; the strip kernels go through their literal-select path, which
+    // is why `uniform_pen` is cleared here -- it steers the strip / wide families only (launch_align_chunk, dtw_generic.hip).
     const bool strict = ctx->distance_mode == 2;
     const bool uniform_pen = (band.ins == band.del) && (band.del == band.mat) && !strict;
     char keybuf[160];
@@ -641,6 +694,7 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
     const apd_batch::TilePlan &plan = cached->second;
     // Poison: every score slot of the rank's slab starts as NaN, so a pair that no kernel writes (a launch cut short, a
     // skipped class) reaches the matrix as NaN and raises APD_ERR_INCOMPLETE in the unpack -- never a stale or zero distance.
+    APD_AFFINITY(ctx, "alignment launches");
     HIP_TRY(ctx, hipMemsetAsync(d_slab, 0xFF, apd_slab_floats(batch->n_seq, world) * sizeof(float), ctx->stream));
     AlignLaunch L{};
     L.d_frames = batch->d_frames; L.frames_bytes = batch->frames_bytes; L.d_seq_off = batch->d_seq_off; L.d_seq_nmax = batch->d_seq_nmax;
@@ -674,14 +728,23 @@ static int align_tiles_impl(apd_context *ctx, const apd_batch *batch, const Band
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done[k], 0));
         }
     if (rc_launch != APD_OK) return rc_launch;
-    if (device_select) {                                                // the literal kernel behind the fast ones: idle unless the flag is raised
-        uint32_t total = 0, w_max = 0, n_max = 0;
-        for (const apd_batch::TileClass &tc : plan.classes) { total += tc.count; w_max = std::max(w_max, tc.w_max); n_max = std::max(n_max, tc.n_max); }
-        L.d_tiles = plan.d_tiles; L.n_tiles = total; L.w_max = w_max; L.n_max = n_max;
-        if (ctx->drop_tiles) L.n_tiles -= std::min(L.n_tiles, ctx->drop_tiles);
-        bool fits = true;
-        const hipError_t e = launch_generic_fallback(L, ctx->stream, &fits);
-        if (e != hipSuccess || !fits) { ctx->last_error = std::string("launch_generic_fallback: ") + (fits ? hipGetErrorString(e) : "band too wide"); return APD_ERR_HIP; }
+    if (device_select) {
+        // the literal kernel behind the fast ones, idle unless the flag is raised -- over the classes a FAST kernel took (a class
+        // that already runs the literal kernel, geometry 0, ignores the flag and must not be aligned twice); neighbouring classes
+        // are contiguous in the tile list and share a launch
+        size_t k = 0;
+        while (k < plan.classes.size()) {
+            if (plan.classes[k].geom_key == 0) { ++k; continue; }
+            uint32_t first = plan.classes[k].first, total = 0, w_max = 0, n_max = 0;
+            for (; k < plan.classes.size() && plan.classes[k].geom_key != 0 && plan.classes[k].first == first + total; ++k) {
+                total += plan.classes[k].count; w_max = std::max(w_max, plan.classes[k].w_max); n_max = std::max(n_max, plan.classes[k].n_max);
+            }
+            L.d_tiles = plan.d_tiles + first; L.n_tiles = total; L.w_max = w_max; L.n_max = n_max;
+            if (ctx->drop_tiles) L.n_tiles -= std::min(L.n_tiles, ctx->drop_tiles);
+            bool fits = true;
+            const hipError_t e = launch_generic_fallback(L, ctx->stream, &fits);
+            if (e != hipSuccess || !fits) { ctx->last_error = std::string("launch_generic_fallback: ") + (fits ? hipGetErrorString(e) : "band too wide"); return APD_ERR_HIP; }
+        }
     }
     if (ctx->timing) { HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream)); ctx->timed = true; }
     return APD_OK;
@@ -707,7 +770,8 @@ extern "C" int apd_unpack_tiles_async(apd_context *ctx, const apd_batch *batch, 
 {
     if (!ctx || !batch || batch->ctx != ctx || !d_gathered || !d_out || world == 0) return APD_ERR_INVALID_ARG;
     const uint32_t n_seq = batch->n_seq;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, bind_device(ctx));
+    APD_AFFINITY(ctx, "unpack launch");
     // the unpack writes every entry, the zero diagonal (alignments.rs:21-23) included; anything it fails to write stays NaN
     HIP_TRY(ctx, hipMemsetAsync(d_out, 0xFF, (size_t)n_seq * n_seq * sizeof(float), ctx->stream));
     HIP_TRY(ctx, launch_unpack(d_gathered, d_out, batch->d_order, n_seq, world, apd_slab_floats(n_seq, world), batch->d_flags,
@@ -737,7 +801,7 @@ extern "C" int apd_align_all(apd_context *ctx, const apd_batch *batch, const apd
 {
     if (!ctx || !batch || !cfg || (!out && batch->n_seq)) return APD_ERR_INVALID_ARG;
     if (batch->n_seq == 0) return APD_OK;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, bind_device(ctx));
     const size_t bytes = (size_t)batch->n_seq * batch->n_seq * sizeof(float);
     float *d_out = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&d_out, bytes));
@@ -823,7 +887,7 @@ extern "C" int apd_device_alloc(apd_context *ctx, uint64_t bytes, void **d_ptr)
 {
     if (!ctx || !d_ptr) return APD_ERR_INVALID_ARG;
     *d_ptr = nullptr;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, bind_device(ctx));
     HIP_TRY(ctx, hipMalloc(d_ptr, std::max<size_t>((size_t)bytes, 16)));
     ctx->buffers.insert(*d_ptr);
     return APD_OK;
@@ -833,7 +897,7 @@ extern "C" int apd_device_free(apd_context *ctx, void *d_ptr)
 {
     if (!ctx) return APD_ERR_INVALID_ARG;
     if (!d_ptr) return APD_OK;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, bind_device(ctx));
     if (ctx->buffers.erase(d_ptr) == 0) return APD_ERR_INVALID_ARG;       // not a buffer of this context (or freed twice)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                      // nothing queued may still use it
     HIP_TRY(ctx, hipFree(d_ptr));
@@ -844,7 +908,7 @@ extern "C" int apd_copy_to_device(apd_context *ctx, void *d_dst, const void *src
 {
     if (!ctx || (bytes && (!d_dst || !src))) return APD_ERR_INVALID_ARG;
     if (bytes == 0) return APD_OK;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, bind_device(ctx));
     HIP_TRY(ctx, hipMemcpyAsync(d_dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return APD_OK;
@@ -854,7 +918,7 @@ extern "C" int apd_copy_to_host(apd_context *ctx, void *dst, const void *d_src, 
 {
     if (!ctx || (bytes && (!dst || !d_src))) return APD_ERR_INVALID_ARG;
     if (bytes == 0) return APD_OK;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, bind_device(ctx));
     HIP_TRY(ctx, hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return APD_OK;
@@ -864,7 +928,7 @@ extern "C" int apd_device_fill(apd_context *ctx, void *d_dst, int byte_value, ui
 {
     if (!ctx || (bytes && !d_dst)) return APD_ERR_INVALID_ARG;
     if (bytes == 0) return APD_OK;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, bind_device(ctx));
     HIP_TRY(ctx, hipMemsetAsync(d_dst, byte_value, (size_t)bytes, ctx->stream));
     return APD_OK;
 }

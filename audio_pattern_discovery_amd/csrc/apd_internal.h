@@ -65,6 +65,8 @@ hipError_t launch_align(const AlignLaunch &L, int geom_key, hipStream_t stream, 
 // The generic kernel over ALL tiles of L as a small persistent grid that does nothing unless *L.d_nonfinite is set.
 // *fits = false (and nothing launched) if the band of L.w_max needs more LDS than a workgroup can have.
 hipError_t launch_generic_fallback(const AlignLaunch &L, hipStream_t stream, bool *fits);
+// true if the literal kernel can hold a band of w_max in LDS AND the runtime grants it that much (the hipFuncSetAttribute is made
+// here, before anything is enqueued: a refusal sends the caller down the host-side choice instead of failing mid-call)
 bool generic_fallback_fits(uint32_t w_max);
 int pick_geometry_key(uint32_t need, uint32_t dim, int variant, bool uniform_pen, bool fast_shift);
 // >= 20000: full-matrix kernel, 20000 + (pairs per wavefront) * 100 + CW, for pairs of at most `rows` x `cols` frames (0 if it does not apply)
@@ -89,6 +91,9 @@ constexpr float kFeatureBound = 0x1p60f;
 
 // comm.hip: called by apd_destroy for every communicator still alive on the context
 void orphan_comm(apd_comm *comm);
+// companions.hip: likewise for the resident feature objects
+void orphan_encoder(apd_encoder *enc);
+void orphan_cepstrum_plan(apd_cepstrum_plan *plan);
 
 // numerics.rs:125-133 on a device array (clustering.hip): radix select of the k-th smallest non-NaN value.
 int device_select(apd_context *ctx, const float *d_x, uint64_t len, uint64_t k, float *value);
@@ -110,7 +115,20 @@ inline uint32_t host_w(const BandSpec &b, uint32_t n, uint32_t m)
     return (band > gap ? band : gap) + 2;       // alignments.rs:173
 }
 
+// ---- device affinity.  Every entry point binds its context's device to the calling thread through bind_device() before it
+// allocates, records an event or launches.  With APD_DEBUG_AFFINITY=1 the library also remembers, per thread, WHICH CONTEXT was
+// bound last, and APD_AFFINITY(ctx) -- placed at the allocations, event records and launches inside the library -- fails the call
+// unless that context is `ctx` and hipGetDevice() agrees.  Comparing contexts, not device numbers, is what lets the one-GPU
+// rehearsals (several "ranks" that all name device 0, tests/test_gpu_multi.py) catch a worker thread that forgot to bind.
+extern thread_local const apd_context *tl_bound_context;
+bool affinity_debug();
+hipError_t bind_device(const apd_context *ctx);
+bool affinity_ok(const apd_context *ctx, const char *where);
+
 }  // namespace apd
+
+#define APD_AFFINITY(ctx, where)                                                                   \
+    do { if (apd::affinity_debug() && !apd::affinity_ok((ctx), (where))) return APD_ERR_HIP; } while (0)
 
 struct apd_context {
     int device = 0;
@@ -129,6 +147,8 @@ struct apd_context {
     // communicators made on this context and not yet destroyed: apd_destroy tears their RCCL side down and orphans them, so
     // that a later apd_comm_destroy only frees the host part (same contract as for batches)
     std::set<apd_comm *> comms;
+    std::set<apd_encoder *> encoders;                 // resident feature objects (companions.hip), same contract
+    std::set<apd_cepstrum_plan *> cepstrum_plans;
     // buffers handed out by apd_device_alloc and not yet freed: apd_destroy releases them (a host whose destructors run in any
     // order -- a garbage collector's -- may free a buffer after its context: apd_device_free on a destroyed context is never
     // called by the mirrors, and nothing leaks)

@@ -936,7 +936,7 @@ __global__ void upgma_init_kernel(UpgmaState st)
 extern "C" int apd_percentile(apd_context *ctx, const float *x, uint64_t len, float perc, int x_on_device, float *value)
 {
     if (!ctx || !value || (len && !x)) return APD_ERR_INVALID_ARG;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, apd::bind_device(ctx));
     const uint64_t k = percentile_index(len, perc);
     if (len == 0 || k >= len) return APD_ERR_INDEX;                       // numbers[n] out of range panics (numerics.rs:132)
     const float *d_x = x;
@@ -956,7 +956,7 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
                               apd_cluster_op *ops, uint32_t *n_ops, uint32_t *roots, uint32_t *n_roots, float *threshold)
 {
     if (!ctx || !n_ops || !n_roots || (n && (!distances || !ops || !roots))) return APD_ERR_INVALID_ARG;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, apd::bind_device(ctx));
     *n_ops = 0; *n_roots = 0;
     const uint64_t nn = (uint64_t)n * n;
     const uint64_t k = percentile_index(nn, perc);

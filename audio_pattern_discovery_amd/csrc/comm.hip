@@ -51,6 +51,7 @@ namespace {
 
 int ensure_gather(apd_context *ctx, size_t need)
 {
+    APD_AFFINITY(ctx, "gather workspace allocation");
     if (ctx->ws_gather && ctx->ws_gather_bytes >= need) return APD_OK;
     if (ctx->ws_gather) { HIP_TRY(ctx, hipFree(ctx->ws_gather)); ctx->ws_gather = nullptr; ctx->ws_gather_bytes = 0; }
     HIP_TRY(ctx, hipMalloc(&ctx->ws_gather, need));
@@ -73,7 +74,7 @@ extern "C" int apd_comm_create(apd_context *ctx, const void *id_bytes, uint32_t 
 {
     if (!ctx || !id_bytes || !out || world == 0 || rank >= world) return APD_ERR_INVALID_ARG;
     *out = nullptr;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, apd::bind_device(ctx));
     apd_comm *c = new (std::nothrow) apd_comm();
     if (!c) return APD_ERR_OOM;
     c->ctx = ctx; c->rank = rank; c->world = world;
@@ -103,7 +104,7 @@ extern "C" int apd_comm_destroy(apd_comm *c)
 {
     if (!c) return APD_ERR_INVALID_ARG;
     if (c->ctx) {                                                        // else: orphaned by apd_destroy, RCCL side already gone
-        hipSetDevice(c->ctx->device);
+        apd::bind_device(c->ctx);
         hipStreamSynchronize(c->ctx->stream);
         if (c->comm) ncclCommDestroy(c->comm);
         c->ctx->comms.erase(c);
@@ -134,7 +135,7 @@ extern "C" int apd_all_gather_async(apd_context *ctx, apd_comm *c, const float *
 {
     if (!ctx || !c || c->ctx != ctx || (count && (!d_send || !d_recv))) return APD_ERR_INVALID_ARG;
     if (count == 0) return APD_OK;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, apd::bind_device(ctx));
     NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, (size_t)count, ncclFloat, c->comm, ctx->stream));
     return APD_OK;
 }
@@ -170,17 +171,14 @@ class WorkerPool {
 public:
     explicit WorkerPool(uint32_t n) : slots_(n > 1 ? n : 0)
     {
-        for (uint32_t i = 0; i < slots_.size(); ++i) threads_.emplace_back([this, i] { loop(i); });
-    }
-    ~WorkerPool()
-    {
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            quit_ = true;
+        try {
+            for (uint32_t i = 0; i < slots_.size(); ++i) threads_.emplace_back([this, i] { loop(i); });
+        } catch (...) {                                                   // a thread that cannot be started (EAGAIN, a process limit):
+            stop();                                                       // the ones already running are joined, not destroyed joinable
+            throw;
         }
-        cv_work_.notify_all();
-        for (std::thread &t : threads_) t.join();
     }
+    ~WorkerPool() { stop(); }
     void run(uint32_t n, const std::function<int(uint32_t)> &f, std::vector<int> &rc)
     {
         rc.assign(n, APD_OK);
@@ -199,6 +197,16 @@ public:
     }
 
 private:
+    void stop()
+    {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            quit_ = true;
+        }
+        cv_work_.notify_all();
+        for (std::thread &t : threads_) if (t.joinable()) t.join();
+        threads_.clear();
+    }
     void loop(uint32_t i)
     {
         uint64_t seen = 0;
@@ -316,15 +324,22 @@ static int apd_multi_create_impl(const int *devices, uint32_t n_devices, apd_mul
         m->collective = "peer-copy fallback: " + why + "; slabs gathered onto devices[0] with hipMemcpyPeerAsync";
         m->slab_ready.assign(n_devices, nullptr);
         for (uint32_t i = 0; i < n_devices; ++i) {
-            hipSetDevice(devices[i]);
+            apd::bind_device(m->ctx[i]);
             if (hipEventCreateWithFlags(&m->slab_ready[i], hipEventDisableTiming) != hipSuccess) rc = APD_ERR_HIP;
         }
-        hipSetDevice(devices[0]);
+        apd::bind_device(m->ctx[0]);
         if (hipEventCreateWithFlags(&m->gathered, hipEventDisableTiming) != hipSuccess) rc = APD_ERR_HIP;
         if (rc != APD_OK) { apd_multi_destroy(m); return rc; }
     }
-    m->pool = new (std::nothrow) WorkerPool(n_devices);
-    if (!m->pool) { apd_multi_destroy(m); return APD_ERR_OOM; }
+    try {
+        m->pool = new WorkerPool(n_devices);
+    } catch (const std::bad_alloc &) {
+        apd_multi_destroy(m);                                             // contexts, communicators, events: nothing leaks
+        return APD_ERR_OOM;
+    } catch (...) {                                                       // std::system_error: a worker thread could not be started
+        apd_multi_destroy(m);
+        return APD_ERR_HIP;
+    }
     *out = m;
     return APD_OK;
 }
@@ -332,14 +347,14 @@ static int apd_multi_create_impl(const int *devices, uint32_t n_devices, apd_mul
 extern "C" int apd_multi_destroy(apd_multi *m)
 {
     if (!m) return APD_ERR_INVALID_ARG;
-    for (apd_context *c : m->ctx) if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); }
+    for (apd_context *c : m->ctx) if (c) { apd::bind_device(c); hipStreamSynchronize(c->stream); }
     delete m->pool;                                                       // joins the workers
     m->pool = nullptr;
     while (!m->batches.empty()) apd_multi_batch_destroy(*m->batches.begin());
     for (ncclComm_t c : m->comms) if (c) ncclCommDestroy(c);
-    for (uint32_t i = 0; i < m->slab_ready.size(); ++i) if (m->slab_ready[i]) { hipSetDevice(m->devices[i]); hipEventDestroy(m->slab_ready[i]); }
-    if (m->gathered) { hipSetDevice(m->devices[0]); hipEventDestroy(m->gathered); }
-    if (m->d_result) { hipSetDevice(m->devices[0]); hipFree(m->d_result); }
+    for (uint32_t i = 0; i < m->slab_ready.size(); ++i) if (m->slab_ready[i] && m->ctx[i]) { apd::bind_device(m->ctx[i]); hipEventDestroy(m->slab_ready[i]); }
+    if (m->gathered && m->ctx[0]) { apd::bind_device(m->ctx[0]); hipEventDestroy(m->gathered); }
+    if (m->d_result && m->ctx[0]) { apd::bind_device(m->ctx[0]); hipFree(m->d_result); }
     for (apd_context *c : m->ctx) if (c) apd_destroy(c);
     delete m;
     return APD_OK;
@@ -415,7 +430,7 @@ static int apd_multi_align_all_async_impl(apd_multi *m, const apd_multi_batch *m
     if (!d_out) {                                                          // the handle's own result matrix on devices[0]
         const size_t need = (size_t)n_seq * n_seq * sizeof(float);
         if (m->result_bytes < need) {
-            hipSetDevice(m->devices[0]);
+            apd::bind_device(m->ctx[0]);
             if (m->d_result) { hipStreamSynchronize(m->ctx[0]->stream); hipFree(m->d_result); m->d_result = nullptr; m->result_bytes = 0; }
             if (hipMalloc((void **)&m->d_result, need) != hipSuccess) return multi_fail(m, APD_ERR_OOM, "device " + std::to_string(m->devices[0]) + ": result matrix");
             m->result_bytes = need;
@@ -423,17 +438,31 @@ static int apd_multi_align_all_async_impl(apd_multi *m, const apd_multi_batch *m
         d_out = m->d_result;
     }
     const bool peer = m->comms.empty();
+    if (peer && m->gathered_valid) {
+        // A larger batch than the last one makes ensure_gather free and re-allocate a device's gather buffer -- while devices[0]'s
+        // stream may still be copying the previous slab out of it (hipFree drains only the owning device's streams).  Wait for that
+        // gather on the host first; the common case (same size again) never gets here.
+        bool grows = false;
+        for (uint32_t i = 0; i < n; ++i) grows |= m->ctx[i]->ws_gather_bytes < gather_bytes;
+        if (grows) {
+            apd::bind_device(m->ctx[0]);
+            if (hipEventSynchronize(m->gathered) != hipSuccess) return multi_fail(m, APD_ERR_HIP, "hipEventSynchronize(gathered)");
+        }
+    }
     // 1. every device: its pair tiles into its slab, in place inside its gather buffer
     std::vector<int> rc;
-    m->pool->run(n, [&](uint32_t i) {
+    m->pool->run(n, [&](uint32_t i) -> int {
         apd_context *c = m->ctx[i];
-        if (hipSetDevice(c->device) != hipSuccess) return (int)APD_ERR_HIP;
+        if (apd::bind_device(c) != hipSuccess) return (int)APD_ERR_HIP;      // worker threads have their own current device
         int r = ensure_gather(c, gather_bytes);
         if (r != APD_OK) return r;
         // peer fallback: devices[0] must have copied this device's previous slab before it is poisoned again
         if (peer && i != 0 && m->gathered_valid && hipStreamWaitEvent(c->stream, m->gathered, 0) != hipSuccess) return (int)APD_ERR_HIP;
         r = apd_align_tiles_async(c, mb->per_device[i], cfg, i, n, (float *)c->ws_gather + (size_t)slab * i);
-        if (r == APD_OK && peer && hipEventRecord(m->slab_ready[i], c->stream) != hipSuccess) r = APD_ERR_HIP;
+        if (r == APD_OK && peer) {
+            APD_AFFINITY(c, "slab_ready event record");
+            if (hipEventRecord(m->slab_ready[i], c->stream) != hipSuccess) r = APD_ERR_HIP;
+        }
         return r;
     }, rc);
     int st = merge_status(m, rc);
@@ -443,7 +472,7 @@ static int apd_multi_align_all_async_impl(apd_multi *m, const apd_multi_batch *m
         ncclResult_t r = ncclGroupStart();
         for (uint32_t i = 0; i < n && r == ncclSuccess; ++i) {
             float *g = (float *)m->ctx[i]->ws_gather;
-            hipSetDevice(m->ctx[i]->device);
+            apd::bind_device(m->ctx[i]);
             r = ncclAllGather(g + (size_t)slab * i, g, (size_t)slab, ncclFloat, m->comms[i], m->ctx[i]->stream);
         }
         const ncclResult_t r2 = ncclGroupEnd();
@@ -451,7 +480,7 @@ static int apd_multi_align_all_async_impl(apd_multi *m, const apd_multi_batch *m
             return multi_fail(m, APD_ERR_COMM, std::string("ncclAllGather: ") + ncclGetErrorString(r != ncclSuccess ? r : r2));
     } else {
         apd_context *c0 = m->ctx[0];
-        hipSetDevice(c0->device);
+        apd::bind_device(c0);
         float *g0 = (float *)c0->ws_gather;
         for (uint32_t i = 1; i < n; ++i) {
             const float *gi = (const float *)m->ctx[i]->ws_gather + (size_t)slab * i;
@@ -484,7 +513,7 @@ static int apd_multi_align_all_impl(apd_multi *m, const apd_multi_batch *mb, con
     int rc = apd_multi_align_all_async(m, mb, cfg, nullptr);
     if (rc != APD_OK) { apd_multi_synchronize(m); return rc; }
     apd_context *c0 = m->ctx[0];
-    hipSetDevice(c0->device);
+    apd::bind_device(c0);
     if (hipMemcpyAsync(out, m->last_result, (size_t)mb->n_seq * mb->n_seq * sizeof(float), hipMemcpyDeviceToHost, c0->stream) != hipSuccess)
         rc = multi_fail(m, APD_ERR_HIP, "device " + std::to_string(c0->device) + ": copy of the matrix to the host failed");
     const int rs = apd_multi_synchronize(m);

@@ -516,7 +516,18 @@ static size_t generic_lds_bytes(uint32_t w_max, int *c_max_out)
     return (size_t)c_max * 64 * 2 * sizeof(float);
 }
 
-bool generic_fallback_fits(uint32_t w_max) { return generic_lds_bytes(w_max, nullptr) <= 160 * 1024; }
+bool generic_fallback_fits(uint32_t w_max)
+{
+    const size_t lds_bytes = generic_lds_bytes(w_max, nullptr);
+    if (lds_bytes > 160 * 1024) return false;                             // gfx950: 160 KB of LDS per workgroup
+    if (lds_bytes > 64 * 1024 &&                                          // beyond the default limit: ask now, not after the fast kernels are enqueued
+        hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_fused_generic_fallback), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
+}
 
 hipError_t launch_generic_fallback(const AlignLaunch &L, hipStream_t stream, bool *fits)
 {

@@ -232,16 +232,32 @@ class DeviceInputs:
             self.d_audio = None
             self.d_src = ctx.upload(inp["frames"])
         self.d_frames = self.d_src if inp["enc_w"] is None else ctx.alloc(total * inp["dim"] * 4)
+        # the feature stage's resident objects, made once (setup, like AlignmentWorkers::new): a step only enqueues the kernels
+        f32p, u64p = C.POINTER(C.c_float), C.POINTER(C.c_uint64)
+        self.plan, self.encoder = C.c_void_p(), C.c_void_p()
+        if self.d_audio is not None:
+            _lib.check(self.L.apd_cepstrum_plan_create(ctx.handle, inp["s_off"].ctypes.data_as(u64p), inp["n"], 256, 128, 18,
+                                                       self.f_off.ctypes.data_as(u64p), C.byref(self.nb), C.byref(self.plan)), ctx.handle)
+        if inp["enc_w"] is not None:
+            _lib.check(self.L.apd_encoder_create(ctx.handle, inp["enc_w"].ctypes.data_as(f32p), inp["enc_b"].ctypes.data_as(f32p),
+                                                 inp["src_dim"], inp["dim"], C.byref(self.encoder)), ctx.handle)
 
     def features(self):
+        """Enqueue-only (apd_cepstrum_batch_async / apd_encode_async): called for device after device from one host thread, the
+        devices' feature kernels still run concurrently."""
         inp, L, ctx = self.inp, self.L, self.ctx
-        f32p, u64p = C.POINTER(C.c_float), C.POINTER(C.c_uint64)
         if self.d_audio is not None:                                 # NDSequence::new on the whole corpus, in HBM
-            self._lib.check(L.apd_cepstrum_batch(ctx.handle, self.d_audio.at(), inp["s_off"].ctypes.data_as(u64p), inp["n"], 256, 128, 18, 1,
-                                                 self.d_src.at(), self.f_off.ctypes.data_as(u64p), C.byref(self.nb)), ctx.handle)
+            self._lib.check(L.apd_cepstrum_batch_async(ctx.handle, self.plan, self.d_audio.at(), self.d_src.at()), ctx.handle)
         if inp["enc_w"] is not None:                                 # NDSequence::encoded on the whole corpus, in HBM
-            self._lib.check(L.apd_encode(ctx.handle, self.d_src.at(), self.total, inp["src_dim"], inp["enc_w"].ctypes.data_as(f32p),
-                                         inp["enc_b"].ctypes.data_as(f32p), inp["dim"], 1, self.d_frames.at()), ctx.handle)
+            self._lib.check(L.apd_encode_async(ctx.handle, self.encoder, self.d_src.at(), self.total, self.d_frames.at()), ctx.handle)
+
+    def close(self):
+        if self.plan:
+            self.L.apd_cepstrum_plan_destroy(self.plan)
+            self.plan = C.c_void_p()
+        if self.encoder:
+            self.L.apd_encoder_destroy(self.encoder)
+            self.encoder = C.c_void_p()
 
 
 def oracle_features(inp, seqs=None):
@@ -415,6 +431,7 @@ def measure_secondary(ctx, name, steps=5, with_census=False):
         out["parity_ok"] = bool(out["parity_ok"] and out["parity_census"]["nonfinite_pattern_equal"] and out["parity_census"]["zero_pattern_equal"]
                                 and same == of)
     L.apd_batch_destroy(batch)
+    dev.close()
     return out
 
 
@@ -812,6 +829,8 @@ def main():
         L.apd_batch_destroy(batch)
     if mbatch is not None:
         mbatch.close()
+    for d in devs:
+        d.close()
     if comm is not None:
         comm.close()
     if dist is not None:

@@ -9,6 +9,8 @@ use std::os::raw::{c_char, c_int, c_void};
 #[repr(C)] pub struct apd_comm { _p: [u8; 0] }
 #[repr(C)] pub struct apd_multi { _p: [u8; 0] }
 #[repr(C)] pub struct apd_multi_batch { _p: [u8; 0] }
+#[repr(C)] pub struct apd_encoder { _p: [u8; 0] }
+#[repr(C)] pub struct apd_cepstrum_plan { _p: [u8; 0] }
 
 pub const APD_OK: c_int = 0;
 pub const APD_ERR_INVALID_ARG: c_int = -1;
@@ -82,6 +84,10 @@ extern "C" {
     pub fn apd_set_variant(ctx: *mut apd_context, variant: c_int) -> c_int;
     pub fn apd_set_distance_mode(ctx: *mut apd_context, mode: c_int, tau: f32) -> c_int;
     pub fn apd_selftest(ctx: *mut apd_context) -> c_int;
+    pub fn apd_selftest_sqrt(ctx: *mut apd_context, first_bits: u32, count: u64, mismatches: *mut u64, first_mismatch: *mut u32,
+                             raw_ulp_hist: *mut u64) -> c_int;
+    pub fn apd_stream_busy(ctx: *mut apd_context, busy: *mut c_int) -> c_int;
+    pub fn apd_debug_affinity_probe(bound: *mut apd_context, checked: *mut apd_context, enabled: *mut c_int) -> c_int;
     pub fn apd_set_fault_injection(ctx: *mut apd_context, drop_tiles: u32) -> c_int;
     // Discovery::alignment_params (discovery.rs:38-45)
     pub fn apd_discovery_alignment_params(cfg: *const apd_align_config, n_size: u64, out: *mut apd_alignment_params) -> c_int;
@@ -158,6 +164,15 @@ extern "C" {
                         on_device: c_int, out: *mut f32, n_frames: *mut u64, n_bins: *mut u32) -> c_int;
     pub fn apd_cepstrum_batch(ctx: *mut apd_context, samples: *const i16, sample_offsets: *const u64, n_seq: u32, fft_size: u32,
                               fft_step: u32, filter_size: u32, on_device: c_int, out: *mut f32, frame_offsets: *mut u64, n_bins: *mut u32) -> c_int;
+    // the same as resident objects + enqueue-only calls
+    pub fn apd_encoder_create(ctx: *mut apd_context, w_encode: *const f32, b_encode: *const f32, d_in: u32, latent: u32,
+                              encoder: *mut *mut apd_encoder) -> c_int;
+    pub fn apd_encoder_destroy(encoder: *mut apd_encoder) -> c_int;
+    pub fn apd_encode_async(ctx: *mut apd_context, encoder: *const apd_encoder, d_x: *const f32, t: u64, d_out: *mut f32) -> c_int;
+    pub fn apd_cepstrum_plan_create(ctx: *mut apd_context, sample_offsets: *const u64, n_seq: u32, fft_size: u32, fft_step: u32,
+                                    filter_size: u32, frame_offsets: *mut u64, n_bins: *mut u32, plan: *mut *mut apd_cepstrum_plan) -> c_int;
+    pub fn apd_cepstrum_plan_destroy(plan: *mut apd_cepstrum_plan) -> c_int;
+    pub fn apd_cepstrum_batch_async(ctx: *mut apd_context, plan: *const apd_cepstrum_plan, d_samples: *const i16, d_out: *mut f32) -> c_int;
     pub fn apd_interesting_ranges(ctx: *mut apd_context, frames: *const f32, t: u64, n_bins: u32, moving_average: u32, perc: f32,
                                   min_len: u64, on_device: c_int, ranges: *mut u64, capacity: u64, n_ranges: *mut u64) -> c_int;
     // formats either side of the path (host only)

@@ -1,5 +1,12 @@
 //! Drop-in for src/clustering.rs of dkohlsdorf/audio_pattern_discovery: Merge, ClusteringOperation and the two associated
 //! functions main.rs calls (clustering.rs:8-25, 40-76, 81-110), bodies on the MI355X.  UNCOMPILED (no Rust toolchain here).
+//!
+//! NOT carried over: `pub fn merge(&mut self) -> ClusteringOperation` (clustering.rs:175-209) and the struct's state it steps
+//! (`parents`, `distances`, `n_instances`: clustering.rs:27-33).  It is `pub` in the reference but called from exactly one place,
+//! the loop inside `clustering` (clustering.rs:104-107); on the GPU that loop runs device-side (three launches per merge, replayed as
+//! a hipGraph) and a host-visible single step would mean a synchronisation and a state download per merge.  A caller that
+//! wants the dendrogram one merge at a time reads the returned `Vec<ClusteringOperation>` in order: entry t IS what the t-th `merge()`
+//! call returns.
 use crate::apd_sys::*;
 use std::collections::HashSet;
 

@@ -45,6 +45,8 @@ typedef enum apd_status {
 typedef struct apd_context apd_context;   /* one GPU + one HIP stream + workspaces */
 typedef struct apd_batch apd_batch;       /* Arc<Vec<NDSequence>> resident in HBM (alignments.rs:12) */
 typedef struct apd_comm apd_comm;         /* this rank's end of an RCCL communicator over the GPUs that share the pair tiles */
+typedef struct apd_encoder apd_encoder;   /* AutoEncoder's w_encode / b_encode resident on a context's GPU (neural.rs:13-17) */
+typedef struct apd_cepstrum_plan apd_cepstrum_plan;   /* window, filterbank, DCT and twiddle tables + the offsets of a corpus, resident */
 
 /* The four Discovery fields the path reads (src/discovery.rs:17-20, project/config/Discovery.toml:17-20). */
 typedef struct apd_align_config {
@@ -73,6 +75,9 @@ typedef struct apd_cluster_op {
 } apd_cluster_op;
 
 /* ---- context ------------------------------------------------------------------------- */
+/* Environment: APD_DEBUG_AFFINITY=1 makes every allocation, event record and launch inside the library check that the calling
+ * thread is bound to THIS context (not merely to the same device number) and fail with APD_ERR_HIP otherwise -- how the
+ * several-ranks-on-one-GPU rehearsals catch a worker thread that forgot hipSetDevice (tests/test_gpu_multi.py). */
 int apd_create(int device, apd_context **ctx);
 /* Also releases the device memory of every batch, and the RCCL side of every communicator, still alive on the context; such
  * a batch / communicator may (and must, for its host part) still be passed to apd_batch_destroy / apd_comm_destroy
@@ -121,6 +126,13 @@ int apd_selftest(apd_context *ctx);
  * The whole f32 range takes about a second (tests/test_gpu_sqrt.py). */
 int apd_selftest_sqrt(apd_context *ctx, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint32_t *first_mismatch,
                       uint64_t *raw_ulp_hist);
+/* TEST HOOK: binds the calling thread to `bound`, then runs the library's affinity check for `checked` (see APD_DEBUG_AFFINITY
+ * above): APD_OK if the check is off (*enabled = 0) or the two are the same context, APD_ERR_HIP with the text in
+ * apd_last_error(checked) otherwise -- also when both contexts sit on the same device, which is the point. */
+int apd_debug_affinity_probe(apd_context *bound, apd_context *checked, int *enabled);
+/* TEST HOOK: *busy = 1 while work enqueued on the context's stream has not finished (hipStreamQuery), 0 once it is idle.  What the
+ * "_async only enqueues" tests assert on, instead of wall-clock ratios. */
+int apd_stream_busy(apd_context *ctx, int *busy);
 /* TEST HOOK (fault injection): the next alignment launches leave the last `drop_tiles` tiles of every kernel class
  * unprocessed, as a launch that is cut short would.  0 = off.  Exists so that the poison / APD_ERR_INCOMPLETE path can
  * be tested (tests/test_gpu_dtw.py); never set it in production. */
@@ -320,6 +332,24 @@ int apd_cepstrum(apd_context *ctx, const int16_t *samples, uint64_t n_samples, u
 int apd_cepstrum_batch(apd_context *ctx, const int16_t *samples, const uint64_t *sample_offsets, uint32_t n_seq,
                        uint32_t fft_size, uint32_t fft_step, uint32_t filter_size, int on_device, float *out,
                        uint64_t *frame_offsets, uint32_t *n_bins);
+
+/* The same two as RESIDENT objects + enqueue-only calls, for hosts that build features repeatedly or on several GPUs (the
+ * reference does it per recording with par_iter, src/main.rs:150-161).  apd_encoder_create / apd_cepstrum_plan_create upload the
+ * weights / build and upload the tables and the corpus' offsets ONCE (blocking; the host arrays are free on return; frame_offsets
+ * and *n_bins are written as apd_cepstrum_batch writes them); apd_encode_async / apd_cepstrum_batch_async then only ENQUEUE the
+ * kernel on the context's stream: device pointers only, no allocation, no table building, no synchronisation
+ * (tests/test_gpu_companions.py::test_async_feature_stage_only_enqueues).  A plan serves every corpus with the same sample offsets.
+ * Objects die with apd_*_destroy, or device-side with their context (apd_destroy), after which only the destroy call is legal.
+ * With several GPUs each context runs the whole corpus' kernel concurrently -- replicated on purpose: the kernels (0.15 ms for cfg 4,
+ * 19 ms for cfg 5, whole corpus) cost less than an all-gather of their output would. */
+int apd_encoder_create(apd_context *ctx, const float *w_encode, const float *b_encode, uint32_t d_in, uint32_t latent,
+                       apd_encoder **encoder);
+int apd_encoder_destroy(apd_encoder *encoder);
+int apd_encode_async(apd_context *ctx, const apd_encoder *encoder, const float *d_x, uint64_t t, float *d_out);
+int apd_cepstrum_plan_create(apd_context *ctx, const uint64_t *sample_offsets, uint32_t n_seq, uint32_t fft_size, uint32_t fft_step,
+                             uint32_t filter_size, uint64_t *frame_offsets, uint32_t *n_bins, apd_cepstrum_plan **plan);
+int apd_cepstrum_plan_destroy(apd_cepstrum_plan *plan);
+int apd_cepstrum_batch_async(apd_context *ctx, const apd_cepstrum_plan *plan, const int16_t *d_samples, float *d_out);
 
 /* NDSequence::interesting_ranges (src/spectrogram.rs:174-216), the "VAT" pre-segmentation that precedes the path:
  * per-frame std, mean of the `moving_average` previous values, percentile threshold, runs longer than min_len.

@@ -7,6 +7,11 @@ import pytest
 # buffers from the library itself (apd_device_alloc).  The one test that shares a stream and tensors with torch
 # (tests/test_gpu_runtime.py) does so in a child process, where torch's bundled runtime is loaded first.
 
+# Every allocation, event record and launch inside the library checks that the calling thread is bound to the context it works on
+# (include/apd.h, APD_DEBUG_AFFINITY): on for the whole suite -- and, through the environment, for the bench.py / harness child
+# processes the tests start -- so that the several-ranks-on-one-GPU rehearsals of tests/test_gpu_multi.py can see a missing bind.
+os.environ.setdefault("APD_DEBUG_AFFINITY", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -185,3 +185,54 @@ def test_interesting_ranges_vat(ctx, oracle, apd):
     with pytest.raises(apd.ApdError) as e:
         seq.interesting_ranges(15, 1.0, 10, ctx)                          # percentile index == len: the reference panics
     assert e.value.status == apd.APD_ERR_INDEX
+
+
+def test_async_feature_stage_only_enqueues(apd, oracle):
+    """apd_encoder / apd_cepstrum_plan: weights, tables and offsets uploaded once; apd_encode_async / apd_cepstrum_batch_async only
+    enqueue (the stream is still busy when they return: no allocation, no table building, no synchronisation inside), and their
+    output is bit-identical to the one-call forms apd_encode / apd_cepstrum_batch."""
+    import ctypes as C
+    L = apd.lib()
+    ctx = apd.Context(0)
+    f32p, u64p = C.POINTER(C.c_float), C.POINTER(C.c_uint64)
+    rng = np.random.default_rng(8)
+    # encoder: 8 M frames of 13 -> 8 (a ~0.3 ms kernel), enqueued 40 times
+    t, d_in, latent = 8_000_000, 13, 8
+    x = rng.standard_normal((t, d_in)).astype(np.float32)
+    w = ((rng.random((d_in, latent)) - 0.5) / latent).astype(np.float32)
+    b = ((rng.random(latent) - 0.5) / latent).astype(np.float32)
+    d_x, d_ref, d_out = ctx.upload(x), ctx.alloc(4 * t * latent), ctx.alloc(4 * t * latent)
+    apd.check(L.apd_encode(ctx.handle, d_x.at(), t, d_in, w.ctypes.data_as(f32p), b.ctypes.data_as(f32p), latent, 1, d_ref.at()), ctx.handle)
+    enc = C.c_void_p()
+    apd.check(L.apd_encoder_create(ctx.handle, w.ctypes.data_as(f32p), b.ctypes.data_as(f32p), d_in, latent, C.byref(enc)), ctx.handle)
+    apd.check(L.apd_encode_async(ctx.handle, enc, d_x.at(), t, d_out.at()), ctx.handle)               # code object loaded
+    ctx.synchronize()
+    for _ in range(40):
+        apd.check(L.apd_encode_async(ctx.handle, enc, d_x.at(), t, d_out.at()), ctx.handle)
+    assert ctx.stream_busy(), "40 encoder launches had all finished when the last call returned"
+    ctx.synchronize()
+    assert np.array_equal(d_out.to_numpy(np.uint32), d_ref.to_numpy(np.uint32))
+    # cepstrum plan: 64 recordings x 262400 samples, enqueued 20 times
+    n, n_samp = 64, 262400
+    audio = rng.integers(-20000, 20000, n * n_samp, dtype=np.int16)
+    s_off = np.arange(n + 1, dtype=np.uint64) * n_samp
+    d_audio = ctx.upload(audio)
+    f_off, f_off2, nb, nb2 = np.zeros(n + 1, np.uint64), np.zeros(n + 1, np.uint64), C.c_uint32(0), C.c_uint32(0)
+    apd.check(L.apd_cepstrum_batch(ctx.handle, d_audio.at(), s_off.ctypes.data_as(u64p), n, 256, 128, 18, 1, None, f_off.ctypes.data_as(u64p), C.byref(nb)), ctx.handle)
+    total = int(f_off[-1])
+    d_cref, d_c = ctx.alloc(4 * total * nb.value), ctx.alloc(4 * total * nb.value)
+    apd.check(L.apd_cepstrum_batch(ctx.handle, d_audio.at(), s_off.ctypes.data_as(u64p), n, 256, 128, 18, 1, d_cref.at(), f_off.ctypes.data_as(u64p), C.byref(nb)), ctx.handle)
+    plan = C.c_void_p()
+    apd.check(L.apd_cepstrum_plan_create(ctx.handle, s_off.ctypes.data_as(u64p), n, 256, 128, 18, f_off2.ctypes.data_as(u64p), C.byref(nb2), C.byref(plan)), ctx.handle)
+    assert np.array_equal(f_off, f_off2) and nb.value == nb2.value == 13
+    apd.check(L.apd_cepstrum_batch_async(ctx.handle, plan, d_audio.at(), d_c.at()), ctx.handle)
+    ctx.synchronize()
+    for _ in range(20):
+        apd.check(L.apd_cepstrum_batch_async(ctx.handle, plan, d_audio.at(), d_c.at()), ctx.handle)
+    assert ctx.stream_busy(), "20 cepstrum launches had all finished when the last call returned"
+    ctx.synchronize()
+    assert np.array_equal(d_c.to_numpy(np.uint32), d_cref.to_numpy(np.uint32))
+    # the objects outlive nothing: destroyed before or after their context, either order is legal
+    apd.check(L.apd_encoder_destroy(enc))
+    ctx.close()
+    apd.check(L.apd_cepstrum_plan_destroy(plan))                   # orphaned by apd_destroy: only the host part is left to free

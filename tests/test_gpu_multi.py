@@ -243,3 +243,50 @@ def test_alignment_workers_mirror_over_devices(apd, oracle):
     w.close()
     assert np.array_equal(first.view(np.uint32), single.view(np.uint32)) and np.array_equal(second.view(np.uint32), single.view(np.uint32))
     assert_parity(first.reshape(48, 48), oracle.align_all(frames, offsets, 0.0625, workers=8))
+
+
+def test_affinity_check_is_on_and_tells_contexts_on_one_device_apart(apd):
+    """APD_DEBUG_AFFINITY=1 (tests/conftest.py): the library checks at every allocation / event / launch that the calling thread is
+    bound to the CONTEXT it works on.  The probe binds one context and checks another: two contexts on the same GPU -- the
+    rehearsal's "ranks" -- are told apart, which is what makes a worker thread that forgot to bind visible on a one-GPU box.
+    Every other test of this file (3, 4 and 8 ranks on device 0) runs with the check armed and must not trip it."""
+    L = apd.lib()
+    a, b = apd.Context(0), apd.Context(0)
+    on = C.c_int(0)
+    assert L.apd_debug_affinity_probe(a.handle, a.handle, C.byref(on)) == apd.APD_OK and on.value == 1
+    assert L.apd_debug_affinity_probe(a.handle, b.handle, C.byref(on)) == apd.APD_ERR_HIP
+    assert b"APD_DEBUG_AFFINITY" in L.apd_last_error(b.handle) and b"another context" in L.apd_last_error(b.handle)
+    # ... and ordinary use of both contexts, interleaved from one thread, passes: every entry point binds for itself
+    x = np.arange(64, dtype=np.float32)
+    da, db = a.upload(x), b.upload(x * 2)
+    assert np.array_equal(da.to_numpy(np.float32), x) and np.array_equal(db.to_numpy(np.float32), x * 2)
+    a.close()
+    b.close()
+
+
+def test_peer_collective_growing_batch_back_to_back(apd):
+    """A small batch, then a larger one, through align_all_async with no synchronisation in between (peer-copy collective, 4 ranks
+    on device 0): the larger slab makes every rank re-allocate its gather buffer while devices[0] may still be copying the previous
+    slabs out of the old ones -- the handle waits for that gather first (csrc/comm.hip).  Both matrices must be right."""
+    from audio_pattern_discovery_amd import sharding
+    cfg = apd.AlignConfig(0.0625, 1.0, 1.0, 1.0)
+    f_small, off_small = synth.make_sequences(40, 60, 13, seed=41)
+    f_big, off_big = synth.make_sequences(400, 120, 13, seed=42)
+    one = sharding.Multi([0])
+    want_small = one.align_all(one.batch(off_small, 13, frames=f_small), cfg)
+    want_big = one.align_all(one.batch(off_big, 13, frames=f_big), cfg)
+    one.close()
+    os.environ["APD_MULTI_COLLECTIVE"] = "peer"
+    try:
+        m = sharding.Multi([0] * 4)
+    finally:
+        del os.environ["APD_MULTI_COLLECTIVE"]
+    b_small, b_big = m.batch(off_small, 13, frames=f_small), m.batch(off_big, 13, frames=f_big)
+    d_small, d_big = m.contexts[0].alloc(4 * 40 * 40), m.contexts[0].alloc(4 * 400 * 400)
+    for _ in range(3):
+        m.align_all_async(b_small, cfg, d_small.ptr)
+        m.align_all_async(b_big, cfg, d_big.ptr)                    # grows the gather buffers right behind the small call
+    m.synchronize()
+    assert np.array_equal(d_small.to_numpy(np.uint32).reshape(40, 40), want_small.view(np.uint32))
+    assert np.array_equal(d_big.to_numpy(np.uint32).reshape(400, 400), want_big.view(np.uint32))
+    m.close()

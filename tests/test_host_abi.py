@@ -267,3 +267,49 @@ def test_rust_binding_declares_every_symbol_with_the_headers_arity():
 
     for name in c_decl:
         assert arity(c_decl[name]) == arity(r_decl[name]), "%s: %d parameters in apd.h, %d in apd_sys.rs" % (name, arity(c_decl[name]), arity(r_decl[name]))
+
+
+def test_rust_binding_modules_call_every_entry_point_with_the_headers_arity():
+    """The drop-in modules of bindings/rust/src (alignments, clustering, spectrogram, neural -- uncompiled: no rustc here) are at
+    least checked call by call: every `apd_*(...)` call passes as many arguments as include/apd.h declares, and the companions'
+    modules exist with the reference's public items (spectrogram.rs:31,99,103,152,167,192; neural.rs:21,30,39,55)."""
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "apd.h")).read(), flags=re.S)
+    c_decl = {m.group(1): m.group(2) for m in re.finditer(r"\b(apd_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S)}
+
+    def arity(params):
+        params = params.strip()
+        return 0 if params in ("", "void") else params.count(",") + 1
+
+    def calls(text):
+        text = re.sub(r"//.*", "", text)
+        for m in re.finditer(r"\b(apd_[a-z0-9_]+)\s*\(", text):
+            depth, i, args, start = 1, m.end(), 0, m.end()
+            while depth and i < len(text):
+                ch = text[i]
+                depth += ch in "([{"
+                depth -= ch in ")]}"
+                if ch == "," and depth == 1:
+                    args += 1
+                i += 1
+            inner = text[start:i - 1].strip()
+            yield m.group(1), (0 if not inner else args + 1)
+
+    src = os.path.join(ROOT, "bindings", "rust", "src")
+    seen = set()
+    for name in ("alignments.rs", "clustering.rs", "spectrogram.rs", "neural.rs"):
+        text = open(os.path.join(src, name)).read()
+        for fn, n_args in calls(text):
+            if fn in c_decl:
+                seen.add(fn)
+                assert n_args == arity(c_decl[fn]), "%s: %s called with %d arguments, apd.h declares %d" % (name, fn, n_args, arity(c_decl[fn]))
+    assert {"apd_cepstrum", "apd_encode", "apd_interesting_ranges", "apd_autoencoder_parse", "apd_autoencoder_copy", "apd_autoencoder_serialize",
+            "apd_multi_align_all", "apd_clustering", "apd_cluster_sets"} <= seen
+    spec, neural = open(os.path.join(src, "spectrogram.rs")).read(), open(os.path.join(src, "neural.rs")).read()
+    for item in ("pub fn new(fft_size: usize, fft_step: usize, filter_size: usize, raw_audio: &AudioData) -> NDSequence", "pub fn vec(&self, t: usize) -> &[f32]",
+                 "pub fn encoded(&self, nn: &AutoEncoder) -> NDSequence", "pub fn len(&self) -> usize", "pub fn at(&self, t: usize, f: usize) -> f32",
+                 "pub fn interesting_ranges(&self, moving_average: usize, perc: f32, min_len: usize) -> Vec<Slice>"):
+        assert item in spec, item
+    for item in ("pub fn n_latent(&self) -> usize", "pub fn from_file(file: &str) -> Result<AutoEncoder>", "pub fn save_file(&self, file: &str) -> Result<()>",
+                 "pub fn predict(&self, x: &Mat) -> Mat"):
+        assert item in neural, item
+    assert "clustering.rs:175" in open(os.path.join(src, "clustering.rs")).read()      # merge's absence is stated, with the reason
