@@ -103,9 +103,10 @@ int apd_set_variant(apd_context *ctx, int variant);
  * mode 0: the difference form sqrt(sum (x_k-y_k)^2).  In the band-form kernels it is computed operation for operation as
  * numerics.rs:114-120 does (every difference, square and partial sum rounded on its own, correctly rounded sqrt), and with
  * unit penalties the fast select picks the reference's predecessor for every non-NaN input: scores are bit-identical to the CPU
- * code, about 2x the time of mode 1.  (The strip kernels of full-band batches keep an fma chain in mode 0: ~2e-7.)
+ * code, about 1.9x the time of mode 1.  (The strip kernels of full-band batches keep an fma chain in mode 0: ~2e-7.)
  * mode 2 (strict): the reference's arithmetic in EVERY kernel family -- band kernels as mode 0, strip kernels through their
- * literal-select path: every score bit-identical to the CPU code.  cfg 3: 1.58 s instead of 0.76 s.
+ * literal-select path: every score bit-identical to the CPU code -- the mode that meets 1e-4 on EVERY entry.  cfg 3: 1.44 s instead
+ * of 0.75 s (the square root is v_sqrt_f32 + an exact two-sided fix-up, checked for every f32 input by apd_selftest_sqrt).
  * With any other penalties the recurrence is discontinuous in its inputs (the penalty added depends on which predecessor wins
  * a strict comparison), so the library ignores the mode and computes operation for operation as numerics.rs:114-120 /
  * alignments.rs:129-160 do: bit-identical to the CPU arithmetic.
