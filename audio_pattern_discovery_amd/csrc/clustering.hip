@@ -188,7 +188,7 @@ struct UpgmaState {
     SegRes *seg;              // [max_items] segment results of the current merge
     uint32_t *n_items;
     uint32_t *done;           // set once the loop condition of clustering.rs:104 fails
-    unsigned long long *dbg;  // APD_DEBUG_UPGMA_TIMING: [n][10] wall_clock64 stamps per merge (nullptr: off)
+    unsigned long long *dbg;  // APD_DEBUG_UPGMA_TIMING: [n][12] wall_clock64 stamps per merge (nullptr: off)
     float threshold;
     uint32_t n;
 };
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
     }
     if (threadIdx.x == 0) {
         if (st.dbg) {
-            unsigned long long *g = st.dbg + (uint64_t)t * 10;
+            unsigned long long *g = st.dbg + (uint64_t)t * 12;
             g[0] = t_entry; g[1] = t_rows; g[2] = t_last; g[3] = t_argmin; g[4] = wall_clock64(); g[5] = ns; g[6] = cp + cq;
         }
         uint32_t op;
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
     const uint32_t nl = *st.n_live;
     const uint32_t group_waves = 2u * ((st.n + 63u) / 64u);
     auto stamp = [&]() __attribute__((always_inline)) {                  // tuning aid: when the last wavefront with work finished
-        if (st.dbg && lane == 0) atomicMax(st.dbg + (uint64_t)(*st.n_ops - 1u) * 10 + 7, (unsigned long long)wall_clock64());
+        if (st.dbg && lane == 0) atomicMax(st.dbg + (uint64_t)(*st.n_ops - 1u) * 12 + 7, (unsigned long long)wall_clock64());
     };
     if (wid < group_waves) {
         const uint32_t dir = wid & 1u, cidx = (wid >> 1) * 64u + lane;
@@ -865,6 +865,11 @@ __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
             }
             f = exact::segment_fn(src, lane, begin, end, es, pack_off != 0xFFFFFFFFu ? st.packed + pack_off : nullptr);
         }
+        if (st.dbg && lane == 0) {
+            unsigned long long *g = st.dbg + (uint64_t)(*st.n_ops - 1u) * 12;
+            atomicMax(g + 9, (unsigned long long)wall_clock64());         // the last segment map of the merge
+            if (item == 0) g[10] = n_items;
+        }
         uint32_t finished = 0;
         if (lane == 0) {
             res->es = (f.a0 >= exact::kCap || f.a1 >= exact::kCap) ? 0u : es;
@@ -878,7 +883,7 @@ __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
             __threadfence();                                             // acquire: the other wavefronts' results, not a stale L1 line
             commit_chain(st, c, sp, lane, st.seg + first);
         }
-        if (st.dbg && lane == 0) atomicMax(st.dbg + (uint64_t)(*st.n_ops - 1u) * 10 + 8, (unsigned long long)wall_clock64());
+        if (st.dbg && lane == 0) atomicMax(st.dbg + (uint64_t)(*st.n_ops - 1u) * 12 + 8, (unsigned long long)wall_clock64());
     }
 }
 
@@ -1043,8 +1048,8 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     // one wavefront per item up to 32768 items (a wavefront that commits a chain must not hold other items back), grid-stride beyond
     const uint32_t segment_blocks = (std::min((2 * n + 3) / 4, 8192u) + 63u) / 64u * 64u;   // groups of 32 wavefronts per XCD
     const bool debug_timing = std::getenv("APD_DEBUG_UPGMA_TIMING") != nullptr;   // tuning aid: phase stamps of every select launch
-    if (debug_timing && hipMalloc((void **)&st.dbg, (size_t)n * 10 * sizeof(unsigned long long)) == hipSuccess)
-        (void)hipMemsetAsync(st.dbg, 0, (size_t)n * 10 * sizeof(unsigned long long), ctx->stream);
+    if (debug_timing && hipMalloc((void **)&st.dbg, (size_t)n * 12 * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemsetAsync(st.dbg, 0, (size_t)n * 12 * sizeof(unsigned long long), ctx->stream);
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     auto enqueue_batch = [&]() {
@@ -1087,21 +1092,22 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     drop_graph();
     const uint32_t cnt = host_state[1];
     if (st.dbg) {
-        std::vector<unsigned long long> g((size_t)n * 10);
+        std::vector<unsigned long long> g((size_t)n * 12);
         if (hipMemcpy(g.data(), st.dbg, g.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess && cnt > 1) {
-            double ph[4] = {0, 0, 0, 0}, stale = 0, merged = 0, chain = 0, seg = 0, gap = 0;
+            double ph[4] = {0, 0, 0, 0}, stale = 0, merged = 0, chain = 0, seg = 0, gap = 0, maps = 0, items = 0;
             for (uint32_t t = 1; t + 1 < cnt; ++t) {                      // stamps: 100 MHz; merge 0 scans every row, the last merge ends the loop
-                const unsigned long long *q = &g[(size_t)t * 10];
+                const unsigned long long *q = &g[(size_t)t * 12];
                 for (int k = 0; k < 4; ++k) ph[k] += (double)(q[k + 1] - q[k]) * 0.01;
                 stale += (double)q[5]; merged += (double)q[6];
                 chain += (double)(q[7] - q[4]) * 0.01;                    // end of select's bookkeeping -> last wavefront of the chain launch
                 seg += (double)(std::max(q[8], q[7]) - q[7]) * 0.01;      // -> last wavefront of the segment launch that had work
-                gap += (double)(g[(size_t)(t + 1) * 10] - std::max(q[8], q[7])) * 0.01;
+                gap += (double)(g[(size_t)(t + 1) * 12] - std::max(q[8], q[7])) * 0.01;
+                if (q[9] > q[7]) { maps += (double)(q[9] - q[7]) * 0.01; items += (double)q[10]; }
             }
             const double m = std::max(1.0, (double)cnt - 2.0);
             std::fprintf(stderr, "[apd] upgma us per merge: select [rows %.2f | arrive %.2f | argmin %.2f | lists %.2f] chain launch %.2f, segment launch %.2f, "
-                                 "to the next select's entry %.2f ; stale rows %.1f, merged list %.1f members\n",
-                         ph[0] / m, ph[1] / m, ph[2] / m, ph[3] / m, chain / m, seg / m, gap / m, stale / m, merged / m);
+                                 "(of which until the last segment map %.2f; %.1f segments per merge) to the next select's entry %.2f ; stale rows %.1f, merged list %.1f members\n",
+                         ph[0] / m, ph[1] / m, ph[2] / m, ph[3] / m, chain / m, seg / m, maps / m, items / m, gap / m, stale / m, merged / m);
         }
         hipFree(st.dbg);
     }

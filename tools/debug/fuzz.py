@@ -22,7 +22,8 @@ for case in range(n_cases):
     integer = bool(rng.random() < 0.4)
     pk = rng.random()
     pens = (1.0, 1.0, 1.0) if pk < 0.5 else ((0.7, 0.7, 0.7) if pk < 0.65 else tuple(float(v) for v in rng.choice([0.25, 0.5, 0.8, 1.0, 1.2, 2.0], 3)))
-    mode = "hybrid" if rng.random() < 0.6 else "exact"
+    mk = rng.random()
+    mode = "hybrid" if mk < 0.5 else ("exact" if mk < 0.7 else "strict")   # strict: every kernel family must return the oracle's BITS
     if length >= 400:
         n_seq = min(n_seq, 14 if length < 1700 else 7)
     frames, offsets = synth.make_sequences(n_seq, length, dim, seed=int(rng.integers(1 << 30)), integer=integer, jitter=jitter,
@@ -43,6 +44,12 @@ for case in range(n_cases):
             rel = float((np.abs(got[nz] - want[nz]) / np.abs(want[nz])).max())
             ok = ok and rel <= 1e-4
     worst = max(worst, rel)
+    if mode == "strict":
+        strict_stat = globals().setdefault("strict_stat", [0, 0])
+        strict_stat[0] += 1
+        same = bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
+        strict_stat[1] += int(same)
+        ok = ok and same
     if pens != (1.0, 1.0, 1.0):
         nonunit = globals().setdefault("nonunit", [0, 0])
         nonunit[0] += 1
@@ -70,5 +77,6 @@ for case in range(n_cases):
         print("FAIL case", case, dict(dim=dim, n_seq=n_seq, length=length, jitter=jitter, pct=pct, integer=integer, pens=pens, mode=mode), "rel", rel, flush=True)
     if case % 20 == 19:
         print("case", case + 1, "worst rel", worst, "fails", fails, "%.0fs" % (time.time() - t0), flush=True)
-print("done: cases", n_cases, "fails", fails, "worst rel", worst, "non-unit penalty cases / bit-exact:", globals().get("nonunit"))
+print("done: cases", n_cases, "fails", fails, "worst rel", worst, "non-unit penalty cases / bit-exact:", globals().get("nonunit"),
+      "strict-mode cases / bit-exact:", globals().get("strict_stat"))
 sys.exit(1 if fails else 0)
