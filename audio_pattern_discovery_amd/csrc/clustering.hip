@@ -136,20 +136,18 @@ __device__ __forceinline__ bool better(const Cand &a, const Cand &b)
     return false;
 }
 
-// The best candidate of a workgroup (blockDim.x a power of two, <= 1024), valid in thread 0: a plain tree over LDS.  (A version
-// that reduced inside the wavefronts with five independent field shuffles first returned a winner whose (l, idp, idq) came from one
-// candidate and (sp, sq) from another when two candidates of one lane tied in l -- found by the tie-laden matrices of
-// tests/test_gpu_clustering.py; the tree has no such failure mode and costs ~2 us.)
-__device__ __forceinline__ Cand block_best(Cand best, Cand *red /* blockDim.x entries of LDS */)
+// Reductions of the select launch: a candidate is packed into ONE 64-bit key whose unsigned order is the order `better` defines,
+// reduced inside the wavefront by shuffles and across wavefronts by one LDS atomic -- two barriers instead of the eleven of a tree.
+// order_key() is monotone over the floats; +0.0 is added first so that -0.0 and +0.0 tie as they do under `<`.
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
 {
-    __syncthreads();                                                      // `red` may still be read from the previous call
-    red[threadIdx.x] = best;
-    __syncthreads();
-    for (int s = (int)blockDim.x / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s && better(red[threadIdx.x + s], red[threadIdx.x])) red[threadIdx.x] = red[threadIdx.x + s];
-        __syncthreads();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int lo = (unsigned int)__shfl_xor((int)(unsigned int)k, o), hi = (unsigned int)__shfl_xor((int)(unsigned int)(k >> 32), o);
+        const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+        k = other < k ? other : k;
     }
-    return red[0];
+    return k;
 }
 
 struct UpgmaState {
@@ -200,9 +198,10 @@ struct UpgmaState {
 // the cached row minima, merge_clusters (clustering.rs:134-141), the merged member list, the op record.
 __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
 {
-    __shared__ Cand red[1024];
     __shared__ Cand win;
-    __shared__ uint32_t is_last;
+    __shared__ uint32_t is_last, kwin, lmin_key;
+    __shared__ float kwin_l;
+    __shared__ unsigned long long kmin;
     if (*st.done != 0) return;
     const uint32_t n = st.n;
     const unsigned long long t_entry = st.dbg ? wall_clock64() : 0ull;
@@ -265,9 +264,20 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
                 for (uint32_t u = 0; u < kIlp; ++u) consider(c0 + u * blockDim.x, v[u], sz[u], idq[u]);
             }
         }
-        best = bl < __builtin_inff() ? Cand{bl, idp, bidq, sp, bsq} : best;
-        best = block_best(best, red);
-        if (threadIdx.x == 0) { st.rbest[sp] = best; st.rb_l[sp] = best.l; st.rscan[sp] = 0; }
+        // (linkage, idq) as one key: smaller linkage first, then smaller idq -- `better` within a row; idq is unique in a row, so
+        // exactly one thread holds the winning key and publishes the column and the linkage that go with it
+        if (threadIdx.x == 0) { kmin = ~0ull; kwin = sp; kwin_l = __builtin_inff(); }
+        __syncthreads();
+        const unsigned long long key = bl < __builtin_inff() ? ((unsigned long long)order_key(bl + 0.0f) << 32) | bidq : ~0ull;
+        const unsigned long long wkey = wave_min_u64(key);
+        if ((threadIdx.x & 63) == 0 && wkey != ~0ull) atomicMin(&kmin, wkey);
+        __syncthreads();
+        if (key != ~0ull && key == kmin) { kwin = bsq; kwin_l = bl; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const Cand found = kmin != ~0ull ? Cand{kwin_l, idp, (uint32_t)kmin, sp, kwin} : best;
+            st.rbest[sp] = found; st.rb_l[sp] = found.l; st.rscan[sp] = 0;
+        }
     }
     // ---- who is last?  (the classic fence + counter: every workgroup's writes above are visible to the one that sees the full count)
     const unsigned long long t_rows = st.dbg ? wall_clock64() : 0ull;
@@ -285,7 +295,8 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
     if (threadIdx.x == 0) { *st.arrive = 0u; *st.n_stale = 0u; *st.r_pending = 0u; *st.n_items = 0u; *st.pack_used = 0u; }
     // global arg-min, two passes over the linkages alone (coalesced, independent loads): the smallest value, then `better` among
     // the rows that hold it (its tie rule needs their ids; almost always a single row)
-    __shared__ float lmin_s[16];
+    if (threadIdx.x == 0) { lmin_key = 0xFFFFFFFFu; kmin = ~0ull; kwin = 0xFFFFFFFFu; }
+    __syncthreads();
     float lmin = __builtin_inff();
     constexpr uint32_t kAhead = 8;                                        // loads in flight per thread
     for (uint32_t c0 = threadIdx.x; c0 < n; c0 += kAhead * blockDim.x) {
@@ -297,10 +308,12 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) lmin = __builtin_fminf(lmin, __shfl_xor(lmin, o));
-    if ((threadIdx.x & 63) == 0) lmin_s[threadIdx.x >> 6] = lmin;
+    if ((threadIdx.x & 63) == 0 && lmin < __builtin_inff()) atomicMin(&lmin_key, order_key(lmin + 0.0f));
     __syncthreads();
-    lmin = lmin_s[0];
-    for (uint32_t k2 = 1; k2 < (blockDim.x >> 6); ++k2) lmin = __builtin_fminf(lmin, lmin_s[k2]);
+    {   // invert order_key: the smallest linkage of the matrix, or +INF if no row has a finite one
+        const uint32_t kk = lmin_key;
+        lmin = kk == 0xFFFFFFFFu ? __builtin_inff() : __builtin_bit_cast(float, (kk & 0x80000000u) ? (kk & 0x7FFFFFFFu) : ~kk);
+    }
     // ... then, among the rows that hold it, the lowest (idp, idq) -- tracked as scalars plus the row, the winner's record read
     // back once.  (Carrying a whole Cand through `if (better(cc, best)) best = cc` here was compiled into a partial assignment:
     // (l, idp, idq) of one row with (sp, sq) of another when a thread met two tied rows -- caught by the tie-laden matrices of
@@ -321,11 +334,16 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
                 }
             }
         }
-    Cand best{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0};
-    if (brow != 0xFFFFFFFFu) best = st.rbest[brow];
-    best = block_best(best, red);
-    if (threadIdx.x == 0) win = best;
-    __syncthreads();
+    {   // (idp, idq) as one key; idp is unique per row, so exactly one thread holds the winning key and publishes its row
+        const unsigned long long key = brow != 0xFFFFFFFFu ? ((unsigned long long)bidp << 32) | bidq : ~0ull;
+        const unsigned long long wkey = wave_min_u64(key);
+        if ((threadIdx.x & 63) == 0 && wkey != ~0ull) atomicMin(&kmin, wkey);
+        __syncthreads();
+        if (key != ~0ull && key == kmin) kwin = brow;
+        __syncthreads();
+        if (threadIdx.x == 0) win = kwin != 0xFFFFFFFFu ? st.rbest[kwin] : Cand{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0};
+        __syncthreads();
+    }
     const unsigned long long t_argmin = st.dbg ? wall_clock64() : 0ull;
     const Cand w = win;
     const uint32_t t = *st.n_ops;
