@@ -660,11 +660,12 @@ struct Chain {
     bool lane_chain;        // a singleton's chain: summed by one lane of the chain launch's group wavefronts
 };
 
+// Chain id w = 2 * (slot of the other cluster) + direction: no trip through the live list to find out what a chain is.
 __device__ __forceinline__ Chain get_chain(const UpgmaState &st, uint32_t w, uint32_t sp)
 {
     Chain c{};
     c.dir = w & 1u;
-    c.s = st.live[w >> 1];
+    c.s = w >> 1;
     if (c.s == sp) return c;                                             // nseg = 0
     const uint32_t sx = c.dir ? c.s : sp, sy = c.dir ? sp : c.s;
     c.lx = st.pool + st.mstart[sx]; c.ly = st.pool + st.mstart[sy];
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
         const uint32_t dir = wid & 1u, cidx = (wid >> 1) * 64u + lane;
         if ((wid >> 1) * 64u >= nl) return;
         // A singleton's slot holds the instance of the same number (slots are instance ids until they merge), so its chain needs no
-        // member-list lookups: live[cidx] -> mcount -> the loads.  (get_chain is only consulted for the record finish_chain wants.)
+        // member-list lookups: live[cidx] -> mcount -> the loads.  (finish_chain only wants the slot and the direction.)
         const uint32_t K = st.mcount[sp], ms = st.mstart[sp];
         const uint32_t own = cidx < nl ? st.live[cidx] : sp;
         const bool active = own != sp && K <= kLaneChain && st.mcount[own] == 1u;
@@ -766,6 +767,12 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
         const float *M = transposed ? st.dT : st.d;
         const uint64_t rs = (dir == 1 && !transposed) ? 1 : st.n, cs = (dir == 1 && !transposed) ? st.n : 1;
         const uint64_t col = active ? (uint64_t)own * cs : 0;
+        // what the end of the chain needs (the row's cached best pair, the sizes and ids of its candidate), requested before the
+        // sum's own loads instead of after them: one memory round trip less on the launch's critical path
+        Cand old{};
+        float sz_own = 0.0f, sz_sp = 0.0f;
+        uint32_t id_own = 0, id_sp = 0, lsq = 0;
+        if (dir == 1u && active) { old = st.rbest[own]; sz_own = st.size[own]; sz_sp = st.size[sp]; id_own = st.id[own]; id_sp = st.id[sp]; lsq = *st.last_sq; }
         float s = 0.0f;                                                  // distance = 0.0 (clustering.rs:154)
         constexpr int kAhead = 32;
         for (uint32_t i0 = 0; i0 < K; i0 += kAhead) {
@@ -778,9 +785,17 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) if (i0 + u < K) s = s + x[u];   // distance += d[x][y] (:162), in order
         }
-        Chain c{};
-        c.s = own; c.dir = dir;
-        if (active) finish_chain(st, c, sp, s);
+        if (active) {                                                    // finish_chain with the operands loaded above
+            if (dir == 1u) {
+                st.S[(uint64_t)own * st.n + sp] = s;
+                if (old.sq == sp || old.sq == lsq) {
+                    if (atomicExch(&st.rscan[own], 1u) == 0u) st.stale[atomicAdd(st.n_stale, 1u)] = own;
+                } else {
+                    const Cand cnd{s / (sz_own * sz_sp), id_own, id_sp, own, sp};
+                    if (better(cnd, old)) { st.rbest[own] = cnd; st.rb_l[own] = cnd.l; }
+                }
+            } else st.S[(uint64_t)sp * st.n + own] = s;
+        }
         stamp();
         return;
     }
@@ -788,11 +803,12 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
     // large for one lane per singleton (more than kLaneChain members), one wavefront per chain against a singleton
     const uint32_t v = wid - group_waves, nb2 = 2u * *st.n_big;
     uint32_t w;
-    if (v < nb2) w = 2u * st.pos[st.big[v >> 1]] + (v & 1u);
+    if (v < nb2) w = 2u * st.big[v >> 1] + (v & 1u);
     else {
         if (st.mcount[sp] <= kLaneChain || v - nb2 >= 2u * nl) return;
-        w = v - nb2;
-        if (st.mcount[st.live[w >> 1]] != 1u) return;                    // covered by the first range
+        const uint32_t s1 = st.live[(v - nb2) >> 1];
+        if (st.mcount[s1] != 1u) return;                                 // covered by the first range
+        w = 2u * s1 + ((v - nb2) & 1u);
     }
     const Chain c = get_chain(st, w, sp);
     if (c.nseg == 0 || c.lane_chain) return;
