@@ -158,6 +158,7 @@ extern "C" int apd_destroy(apd_context *ctx)
     if (!ctx) return APD_ERR_INVALID_ARG;
     bind_device(ctx);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->pair_batch) { apd_batch_destroy(ctx->pair_batch); ctx->pair_batch = nullptr; }   // apd_align_pair's own (nobody else holds it)
     for (apd_batch *b : ctx->batches) { release_batch_device_memory(b); b->ctx = nullptr; }   // orphans: see apd_batch_destroy
     ctx->batches.clear();
     for (apd_comm *c : ctx->comms) apd::orphan_comm(c);
@@ -826,15 +827,27 @@ extern "C" int apd_align_pair(apd_context *ctx, const float *x, uint64_t n, cons
     std::memcpy(frames.data(), x, n * (size_t)dim * sizeof(float));
     std::memcpy(frames.data() + n * (size_t)dim, y, m * (size_t)dim * sizeof(float));
     const uint64_t offsets[3] = {0, n, n + m};
-    apd_batch *b = nullptr;
-    int rc = apd_batch_create(ctx, frames.data(), offsets, 2, dim, 0, &b);
-    if (rc) return rc;
+    // A host that loops over Alignment::construct_alignment (alignments.rs:165) mostly aligns pairs of the SAME lengths (fixed
+    // windows): the context keeps the last pair's two-sequence batch and refills it (no allocation, no plan rebuild) when the next
+    // pair has the same (n, m, dim); any other shape replaces it.
+    int rc = APD_OK;
+    if (ctx->pair_batch && (ctx->pair_n != n || ctx->pair_m != m || ctx->pair_dim != dim)) { apd_batch_destroy(ctx->pair_batch); ctx->pair_batch = nullptr; }
+    if (!ctx->pair_batch) {
+        rc = apd_batch_create(ctx, frames.data(), offsets, 2, dim, 0, &ctx->pair_batch);
+        if (rc) { ctx->pair_batch = nullptr; return rc; }
+        ctx->pair_n = n; ctx->pair_m = m; ctx->pair_dim = dim;
+    } else {
+        rc = apd_batch_refill(ctx, ctx->pair_batch, frames.data(), 0);   // host frames: the refill has consumed them when it returns
+        if (rc) return rc;
+    }
+    apd_batch *b = ctx->pair_batch;
     BandSpec band{};
     band.use_explicit = 1;
     band.explicit_band = params->warping_band > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)params->warping_band;
     band.ins = params->insertion_penalty; band.del = params->deletion_penalty; band.mat = params->match_penalty;
-    float *d_out = nullptr;
-    if (hipMalloc((void **)&d_out, 4 * sizeof(float)) != hipSuccess) { apd_batch_destroy(b); return APD_ERR_OOM; }
+    rc = ensure_ws(ctx, &ctx->ws_misc, &ctx->ws_misc_bytes, 256);
+    if (rc) return rc;
+    float *d_out = (float *)ctx->ws_misc;
     rc = align_all_device_impl(ctx, b, band, d_out);
     float host[4] = {0, 0, 0, 0};
     if (rc == APD_OK) {
@@ -842,8 +855,6 @@ extern "C" int apd_align_pair(apd_context *ctx, const float *x, uint64_t n, cons
         if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); rc = APD_ERR_HIP; }
         else rc = sync_and_report(ctx);
     }
-    hipFree(d_out);
-    apd_batch_destroy(b);
     if (rc == APD_OK) *score = host[1];                                   // out[0*2+1] = score(x, y)
     return rc;
 }

@@ -165,6 +165,9 @@ struct apd_context {
     void *ws_gather = nullptr; size_t ws_gather_bytes = 0;   // gathered slabs of apd_align_all_sharded_async
     uint32_t *d_status = nullptr;     // sticky device word: bit 0 = an unpack met an unwritten (poisoned) pair score
     uint32_t drop_tiles = 0;          // fault injection (apd_set_fault_injection)
+    apd_batch *pair_batch = nullptr;  // apd_align_pair: the last pair's two-sequence batch, refilled while (n, m, dim) repeat
+    uint64_t pair_n = 0, pair_m = 0;
+    uint32_t pair_dim = 0;
 };
 
 struct apd_batch {

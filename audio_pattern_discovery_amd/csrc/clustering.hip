@@ -122,6 +122,13 @@ namespace {
 
 // ---------------------------------------------------------------------------------------- UPGMA
 
+// Agent-scope relaxed accesses (sc1 on gfx950: the store goes through to the point every XCD sees, the load does not stop at this CU's
+// L1 or this XCD's L2).  What one wavefront hands to another INSIDE a launch -- segment results, packed copies -- travels through these,
+// so that the hand-over needs no agent-scope FENCE: a release fence writes the whole XCD's L2 back, and two thousand of them per
+// merge (one per segment) were 40 % of the segment launch.
+template <typename T> __device__ __forceinline__ void store_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ T load_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 struct Cand { float l; uint32_t idp, idq, sp, sq; };
 // one segment of a long chain (see "the new cluster's row and column of S"): the predicted running sum at its start, the
 // exponent the map was computed under (0: no valid map) and the map S -> S + (S odd ? a1 : a0)
@@ -178,6 +185,10 @@ struct UpgmaState {
     float *R;                 // [n][n] R[x][slot]: approximate sum of d[x][y] over the members y of the cluster in `slot`
     uint32_t *item_start;     // [2 n] first work item (segment) of a segmented chain of the current merge
     uint32_t *item_chain;     // [max_items] chain of every work item
+    uint32_t *band_items;     // [8][max_items] the items of every XCD's band (see upgma_segment_kernel); band_count[8]
+    uint32_t *band_count;
+    uint32_t band_cap;
+    uint32_t ablate;          // timing-only experiments (results wrong): 1 no commit, 2 no segment maps
     uint32_t *seg_done;       // [2 n] finished segments of a segmented chain
     float *packed;            // contiguous copies of the segments the commit pass is likely to re-walk (nullptr: off)
     uint32_t *pack_used;      // bump allocator of `packed`, reset per merge
@@ -293,6 +304,7 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
     if (is_last == 0u) return;
     const unsigned long long t_last = st.dbg ? wall_clock64() : 0ull;
     if (threadIdx.x == 0) { *st.arrive = 0u; *st.n_stale = 0u; *st.r_pending = 0u; *st.n_items = 0u; *st.pack_used = 0u; }
+    if (threadIdx.x < 8) st.band_count[threadIdx.x] = 0u;
     // global arg-min, two passes over the linkages alone (coalesced, independent loads): the smallest value, then `better` among
     // the rows that hold it (its tie rule needs their ids; almost always a single row)
     if (threadIdx.x == 0) { lmin_key = 0xFFFFFFFFu; kmin = ~0ull; kwin = 0xFFFFFFFFu; }
@@ -524,9 +536,9 @@ struct PackedSrc {
     __device__ __forceinline__ void load_run(uint64_t first, uint64_t total, float (&x)[K]) const
     {
 #pragma unroll
-        for (int j = 0; j < K; ++j) x[j] = first + j < total ? p[first + j] : 0.0f;
+        for (int j = 0; j < K; ++j) x[j] = first + j < total ? load_agent(p + first + j) : 0.0f;   // written by another wavefront of this launch
     }
-    __device__ __forceinline__ float load_one(uint64_t e, uint64_t) const { return p[e]; }
+    __device__ __forceinline__ float load_one(uint64_t e, uint64_t) const { return load_agent(p + e); }
 };
 
 // Elements [pos, total) of a chain are added, in order, into the one f32 accumulator `s` -- by one wavefront; every lane
@@ -618,7 +630,7 @@ __device__ Fn segment_fn(const GatherSrc src, uint32_t lane, uint64_t begin, uin
             const uint32_t xb = __builtin_bit_cast(uint32_t, x[j]);
             bad |= xb > 0x7F800000u;
             f = compose(f, element(xb, es));                             // padding (+0.0) is the identity
-            if (pack && (uint32_t)j < cnt) pack[(e - begin) + j] = x[j];
+            if (pack && (uint32_t)j < cnt) store_agent(pack + (e - begin) + j, x[j]);
         }
         e += cnt;
     }
@@ -821,7 +833,18 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
     uint32_t base = 0;
     if (lane == 0) { base = atomicAdd(st.n_items, c.nseg); st.item_start[w] = base; st.seg_done[w] = 0u; }
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    for (uint32_t j = lane; j < c.nseg; j += 64) st.item_chain[base + j] = w;
+    // Every segment also goes onto the work list of ONE XCD, chosen by where in the source matrix it reads: a dir-0 chain reads the
+    // rows of d that belong to the new cluster -- band = (first row of the segment) * 8 / |Ck|; a dir-1 chain reads ALL of those rows
+    // of the transposed copy at the columns of its own members -- band = (first column) * 8 / n.  The segments of different chains
+    // interleave inside those rows (every cache line of a row holds columns of several clusters), and gathering them is bound by
+    // miss latency x outstanding requests: with one eighth of the K x n source per XCD (3.4 MB at K = 424, n = 16384) the lines a
+    // segment needs have usually been brought into that XCD's L2 by a neighbour.  A locality hint only: any assignment is correct.
+    for (uint32_t j = lane; j < c.nseg; j += 64) {
+        st.item_chain[base + j] = w;
+        const uint32_t a0 = j * c.rps;
+        const uint32_t band = c.dir == 0u ? (uint32_t)(((uint64_t)a0 * 8u) / c.cx) : (uint32_t)(((uint64_t)c.lx[a0] * 8u) / st.n);
+        st.band_items[(uint64_t)min(band, 7u) * st.band_cap + atomicAdd(&st.band_count[min(band, 7u)], 1u)] = base + j;
+    }
     predict_chain(st, c, sp, lane, st.seg + base);
     stamp();
 }
@@ -840,7 +863,10 @@ __device__ void commit_chain(const UpgmaState &st, const Chain &c, uint32_t sp, 
     float s = 0.0f;
     for (uint32_t j0 = 0; j0 < c.nseg; j0 += 64) {
         SegRes mine{};                                                   // lane t holds segment j0 + t
-        if (j0 + lane < c.nseg) mine = res[j0 + lane];
+        if (j0 + lane < c.nseg) {
+            const SegRes *r = res + j0 + lane;
+            mine.es = load_agent(&r->es); mine.a0 = load_agent(&r->a0); mine.a1 = load_agent(&r->a1); mine.pack = load_agent(&r->pack);
+        }
         const uint32_t cnt = min(64u, c.nseg - j0);
         for (uint32_t t = 0; t < cnt; ++t) {
             const uint32_t es_j = (uint32_t)__builtin_amdgcn_readlane((int)mine.es, (int)t);
@@ -870,11 +896,13 @@ __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
     if (sp == 0xFFFFFFFFu || *st.done != 0) return;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n_items = *st.n_items;
-    const uint32_t xcd = blockIdx.x & 7u, v = (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6);   // v-th wavefront of this XCD
-    const uint32_t groups_per_round = (gridDim.x >> 3) * 4u / 32u * 8u;                        // gridDim.x is a multiple of 64
-    for (uint32_t g = (v >> 5) * 8u + xcd; (uint64_t)g * 32u < n_items; g += groups_per_round) {
-        const uint32_t item = g * 32u + (v & 31u);
-        if (item >= n_items) break;
+    if (n_items == 0u) return;
+    const uint32_t xcd = blockIdx.x & 7u, v = (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6);   // v-th wavefront of this XCD (blocks b and b + 8 share one)
+    const uint32_t waves_per_xcd = (gridDim.x >> 3) * 4u;                                      // gridDim.x is a multiple of 64
+    const uint32_t mine = st.band_count[xcd];
+    const uint32_t *list = st.band_items + (uint64_t)xcd * st.band_cap;
+    for (uint32_t k = v; k < mine; k += waves_per_xcd) {
+        const uint32_t item = list[k];
         const uint32_t w = st.item_chain[item];
         const Chain c = get_chain(st, w, sp);
         const exact::GatherSrc src = chain_src(st, c);
@@ -883,7 +911,7 @@ __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
         const uint32_t pb = __builtin_bit_cast(uint32_t, res->predicted), es = pb >> 23;
         exact::Fn f{exact::kCap, exact::kCap};
         uint32_t pack_off = 0xFFFFFFFFu;
-        if (es >= 1u && es <= 254u) {
+        if (es >= 1u && es <= 254u && !(st.ablate & 2u)) {
             const uint64_t begin = (uint64_t)j * c.rps * c.cy, end = min<uint64_t>(begin + (uint64_t)c.rps * c.cy, (uint64_t)c.cx * c.cy);
             const uint32_t len = (uint32_t)(end - begin);
             // will the commit re-walk this segment?  (the next segment's prediction is this segment's predicted end)
@@ -902,20 +930,21 @@ __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
         if (st.dbg && lane == 0) {
             unsigned long long *g = st.dbg + (uint64_t)(*st.n_ops - 1u) * 12;
             atomicMax(g + 9, (unsigned long long)wall_clock64());         // the last segment map of the merge
-            if (item == 0) g[10] = n_items;
+            if (k == 0 && xcd == 0) g[10] = n_items;
         }
         uint32_t finished = 0;
         if (lane == 0) {
-            res->es = (f.a0 >= exact::kCap || f.a1 >= exact::kCap) ? 0u : es;
-            res->a0 = f.a0; res->a1 = f.a1;
-            res->pack = pack_off;
+            store_agent(&res->es, (f.a0 >= exact::kCap || f.a1 >= exact::kCap) ? 0u : es);
+            store_agent(&res->a0, f.a0); store_agent(&res->a1, f.a1);
+            store_agent(&res->pack, pack_off);
         }
-        __threadfence();                                                 // this segment's map and packed copy (every lane's stores) first ...
+        // this segment's map and packed copy (agent-scope stores of every lane) have been performed ...
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // (a wait for this wavefront's stores; no cache write-back)
         if (lane == 0) finished = atomicAdd(&st.seg_done[w], 1u) + 1u;   // ... then the count
         finished = (uint32_t)__builtin_amdgcn_readfirstlane((int)finished);
-        if (finished == c.nseg) {
-            __threadfence();                                             // acquire: the other wavefronts' results, not a stale L1 line
-            commit_chain(st, c, sp, lane, st.seg + first);
+        if (finished == c.nseg && !(st.ablate & 1u)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            commit_chain(st, c, sp, lane, st.seg + first);               // reads the other wavefronts' results with agent-scope loads
         }
         if (st.dbg && lane == 0) atomicMax(st.dbg + (uint64_t)(*st.n_ops - 1u) * 12 + 8, (unsigned long long)wall_clock64());
     }
@@ -963,6 +992,7 @@ __global__ void upgma_init_kernel(UpgmaState st)
         *st.n_live = st.n;
         *st.n_big = 0;
         *st.n_stale = st.n; *st.arrive = 0; *st.r_pending = 0; *st.n_items = 0; *st.pack_used = 0; *st.last_sq = 0;
+        for (int b = 0; b < 8; ++b) st.band_count[b] = 0;
         *st.n_ops = 0;
         *st.pool_used = st.n;
         *st.last_sp = 0xFFFFFFFFu;
@@ -1020,7 +1050,7 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
                  o_id = carve(bytes_u), o_live = carve(bytes_u), o_mstart = carve(bytes_u), o_mcount = carve(bytes_u), o_rscan = carve(bytes_u),
                  o_pos = carve(bytes_u), o_big = carve(bytes_u), o_bpos = carve(bytes_u), o_rbl = carve(bytes_f), o_stale = carve(bytes_u),
                  o_rbest = carve((size_t)n * sizeof(Cand)), o_ops = carve((size_t)n * sizeof(apd_cluster_op)), o_seg = carve(bytes_seg),
-                 o_istart = carve(bytes_items), o_sdone = carve(bytes_items), o_ichain = carve(bytes_ichain), o_packed = carve(bytes_packed),
+                 o_istart = carve(bytes_items), o_sdone = carve(bytes_items), o_ichain = carve(bytes_ichain), o_band = carve(8 * bytes_ichain), o_packed = carve(bytes_packed),
                  o_T = carve(bytes_S), o_words = carve(256);
     HIP_TRY(ctx, hipMalloc((void **)&pool, off));
     st.S = (float *)(pool + o_S);
@@ -1044,6 +1074,8 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     st.item_start = (uint32_t *)(pool + o_istart);
     st.seg_done = (uint32_t *)(pool + o_sdone);
     st.item_chain = (uint32_t *)(pool + o_ichain);
+    st.band_items = (uint32_t *)(pool + o_band);
+    st.band_cap = (uint32_t)max_items;
     st.packed = (float *)(pool + o_packed);
     st.pack_capacity = (uint32_t)(bytes_packed / sizeof(float));
     float *d_T = (float *)(pool + o_T);
@@ -1051,7 +1083,7 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     st.n_live = (uint32_t *)(pool + o_words); st.n_ops = st.n_live + 1; st.done = st.n_live + 2;     // host_state reads these three
     st.pool_used = st.n_live + 3; st.last_sp = st.n_live + 4; st.last_sq = st.n_live + 5; st.n_items = st.n_live + 6;
     st.pack_used = st.n_live + 7; st.n_stale = st.n_live + 8; st.arrive = st.n_live + 9; st.r_pending = st.n_live + 10;
-    st.n_big = st.n_live + 11;
+    st.n_big = st.n_live + 11; st.band_count = st.n_live + 16;
     auto fail = [&](int rc) { hipFree(pool); if (st.dbg) hipFree(st.dbg); return rc; };
     if (distances_on_device) st.d = distances;
     else {
@@ -1097,7 +1129,9 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return fail(APD_ERR_HIP); }
     // the legacy default stream cannot be captured: then the batch is enqueued directly
-    bool use_graph = ctx->stream != nullptr && hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (const char *v = std::getenv("APD_UPGMA_ABLATE")) st.ablate = (uint32_t)std::atoi(v);   // timing-only: results become wrong
+    bool use_graph = ctx->stream != nullptr && std::getenv("APD_UPGMA_NO_GRAPH") == nullptr &&   // (the env: plain launches, for profilers that choke on graphs)
+                     hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
     if (use_graph) {
         enqueue_batch();
         use_graph = hipStreamEndCapture(ctx->stream, &graph) == hipSuccess && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;

@@ -150,6 +150,14 @@ def test_single_pair_api_matches_oracle(ctx, oracle):
         a.construct_alignment(x, y, AlignmentParams(band, 0.8, 1.2, 1.0))
         want = oracle.dtw_pair(x, y, band, 0.8, 1.2, 1.0)
         assert_parity(np.array([a.score()]), np.array([want]))
+    # the same shape again and again with new values (a host looping over fixed windows): the context refills its pair batch
+    a = Alignment(ctx)
+    for k in range(6):
+        x = rng.standard_normal((70, 13)).astype(np.float32) * (k + 1)
+        y = rng.standard_normal((64, 13)).astype(np.float32)
+        for band in (5, 9):
+            a.construct_alignment(x, y, AlignmentParams(band, 1.0, 1.0, 1.0))
+            assert_parity(np.array([a.score()]), np.array([oracle.dtw_pair(x, y, band)]))
     assert Alignment(ctx).score() == float("inf")       # Alignment::new().score(), alignments.rs:117-118
     # long sequences, unit penalties: an explicit band that never binds (full-matrix kernel, several column passes, either
     # orientation), one that binds beyond a wavefront (wide kernel), one within a wavefront (systolic)
