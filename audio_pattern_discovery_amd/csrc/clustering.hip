@@ -130,9 +130,12 @@ template <typename T> __device__ __forceinline__ void store_agent(T *p, T v) { _
 template <typename T> __device__ __forceinline__ T load_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct Cand { float l; uint32_t idp, idq, sp, sq; };
-// one segment of a long chain (see "the new cluster's row and column of S"): the predicted running sum at its start, the
-// exponent the map was computed under (0: no valid map) and the map S -> S + (S odd ? a1 : a0)
-struct SegRes { float predicted; uint32_t es, a0, a1, pack, pad0, pad1, pad2; };   // pack: offset of the segment's contiguous copy, or ~0
+// one segment of a long chain (see "the new cluster's row and column of S"): the predicted running sum at its start, the exponent
+// es the maps were computed under (0: none), and for each of its four SUB-BLOCKS (the shares of lanes 0-15, 16-31, 32-47, 48-63) the
+// map S -> S + (S odd ? a1 : a0) under es (a0 / a1) and under es + 1 (b0 / b1): when the running sum changes binade inside the
+// segment, the commit walks the one sub-block that holds the change and goes on with the es + 1 maps -- a quarter of a segment
+// re-walked per binade change instead of the whole of it.  A map that cannot be used holds kCap.
+struct SegRes { float predicted; uint32_t es, pack, pad; uint32_t a0[4], a1[4], b0[4], b1[4]; };   // pack: offset of the segment's contiguous copy, or ~0
 
 __device__ __forceinline__ bool better(const Cand &a, const Cand &b)
 {
@@ -188,7 +191,8 @@ struct UpgmaState {
     uint32_t *band_items;     // [8][max_items] the items of every XCD's band (see upgma_segment_kernel); band_count[8]
     uint32_t *band_count;
     uint32_t band_cap;
-    uint32_t ablate;          // timing-only experiments (results wrong): 1 no commit, 2 no segment maps
+    uint32_t short_chain;     // chains up to this many elements are walked whole by one wavefront
+    uint32_t ablate;          // timing-only experiments (results wrong): 1 no commit, 2 no segment maps, 4 no segment work at all, 8 no predict
     uint32_t *seg_done;       // [2 n] finished segments of a segmented chain
     float *packed;            // contiguous copies of the segments the commit pass is likely to re-walk (nullptr: off)
     uint32_t *pack_used;      // bump allocator of `packed`, reset per merge
@@ -609,17 +613,19 @@ __device__ float ordered_walk(const Src src, uint32_t lane, uint64_t pos, uint64
     return s;
 }
 
-// The map of elements [begin, end) of the chain on the integer mantissa of a sum whose biased exponent is `es` and stays
-// `es` throughout: every lane composes its own contiguous share (no cross-lane traffic until one ordered reduction at the
-// end).  {kCap, kCap} if an element cannot be expressed (negative, NaN, or large enough to leave the binade by itself).
-// The elements are also written to pack[0 .. end - begin) for whoever has to re-walk the segment.
-__device__ Fn segment_fn(const GatherSrc src, uint32_t lane, uint64_t begin, uint64_t end, uint32_t es, float *__restrict__ pack)
+// The maps of elements [begin, end) of the chain on the integer mantissa of a sum whose biased exponent is `es` (f) or `es + 1` (g)
+// and stays so: every lane composes its own contiguous share (no cross-lane traffic until the ordered reduction at the end), the
+// sixteen lanes of a DPP row compose into that sub-block's map.  {kCap, kCap} where an element cannot be expressed (negative, NaN, or
+// large enough to leave the binade by itself).  The elements are also written to pack[0 .. end - begin) for whoever has to re-walk.
+struct BlockMaps { Fn f[4], g[4]; };
+__device__ BlockMaps segment_fn(const GatherSrc src, uint32_t lane, uint64_t begin, uint64_t end, uint32_t es, float *__restrict__ pack)
 {
     const uint64_t len = end - begin, share = (len + 63) / 64;
     uint64_t e = begin + share * lane;
     const uint64_t stop = min<uint64_t>(e + share, end);
-    Fn f{0u, 0u};
+    Fn f{0u, 0u}, g{0u, 0u};
     bool bad = false;
+    const bool up_ok = es + 1u <= 254u;                                  // es + 1 = 255 is +INF: no integer map there
     constexpr int kUnroll = 8;                                           // loads of 8 elements in flight per lane
     while (e < stop) {
         float x[kUnroll];
@@ -630,15 +636,29 @@ __device__ Fn segment_fn(const GatherSrc src, uint32_t lane, uint64_t begin, uin
             const uint32_t xb = __builtin_bit_cast(uint32_t, x[j]);
             bad |= xb > 0x7F800000u;
             f = compose(f, element(xb, es));                             // padding (+0.0) is the identity
+            g = compose(g, element(xb, es + 1u));
             if (pack && (uint32_t)j < cnt) store_agent(pack + (e - begin) + j, x[j]);
         }
         e += cnt;
     }
     if (bad) f.a0 = f.a1 = kCap;
-    f = wave_scan(f);                                                    // lane 63 holds the composition of all shares, in order
-    Fn out;
-    out.a0 = (uint32_t)__builtin_amdgcn_readlane((int)f.a0, 63);
-    out.a1 = (uint32_t)__builtin_amdgcn_readlane((int)f.a1, 63);
+    if (bad || !up_ok) g.a0 = g.a1 = kCap;
+    // inclusive prefix inside each row of 16 lanes: lane 15 of a row holds the row's composition, in order
+    auto row_scan = [](Fn v) __attribute__((always_inline)) {
+        v = compose(dpp_fn<0x111, 0xf>(v), v);   // row_shr:1
+        v = compose(dpp_fn<0x112, 0xf>(v), v);   // row_shr:2
+        v = compose(dpp_fn<0x114, 0xf>(v), v);   // row_shr:4
+        v = compose(dpp_fn<0x118, 0xf>(v), v);   // row_shr:8
+        return v;
+    };
+    f = row_scan(f);
+    g = row_scan(g);
+    BlockMaps out;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        out.f[b].a0 = (uint32_t)__builtin_amdgcn_readlane((int)f.a0, 16 * b + 15); out.f[b].a1 = (uint32_t)__builtin_amdgcn_readlane((int)f.a1, 16 * b + 15);
+        out.g[b].a0 = (uint32_t)__builtin_amdgcn_readlane((int)g.a0, 16 * b + 15); out.g[b].a1 = (uint32_t)__builtin_amdgcn_readlane((int)g.a1, 16 * b + 15);
+    }
     return out;
 }
 
@@ -685,7 +705,7 @@ __device__ __forceinline__ Chain get_chain(const UpgmaState &st, uint32_t w, uin
     c.slot_y = sy;
     const uint64_t len = (uint64_t)c.cx * c.cy;
     if (len <= kLaneChain && (c.dir ? c.cx : c.cy) == 1u) { c.rps = c.cx; c.nseg = 1; c.lane_chain = true; return c; }
-    if (len <= kShortChain) { c.rps = c.cx; c.nseg = 1; return c; }
+    if (len <= st.short_chain) { c.rps = c.cx; c.nseg = 1; return c; }
     c.rps = c.cy >= kSegElems ? 1u : kSegElems / c.cy;
     c.nseg = (c.cx + c.rps - 1) / c.rps;
     return c;
@@ -839,6 +859,7 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
     // interleave inside those rows (every cache line of a row holds columns of several clusters), and gathering them is bound by
     // miss latency x outstanding requests: with one eighth of the K x n source per XCD (3.4 MB at K = 424, n = 16384) the lines a
     // segment needs have usually been brought into that XCD's L2 by a neighbour.  A locality hint only: any assignment is correct.
+    if (st.ablate & 8u) return;
     for (uint32_t j = lane; j < c.nseg; j += 64) {
         st.item_chain[base + j] = w;
         const uint32_t a0 = j * c.rps;
@@ -857,36 +878,51 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
 // The wavefront that finishes the LAST segment of a chain (atomic counter behind a fence) commits the chain: the true sum through
 // the segments, in order -- a segment whose assumed exponent matches and whose map keeps the sum inside the binade is applied in
 // O(1), any other one is re-walked element by element from the true sum.
-__device__ void commit_chain(const UpgmaState &st, const Chain &c, uint32_t sp, uint32_t lane, const SegRes *res)
+__device__ void commit_chain(const UpgmaState &st, const Chain &c, uint32_t sp, uint32_t lane, const SegRes *res, uint32_t *rewalks = nullptr)
 {
+    uint32_t n_rewalk = 0;
     const uint64_t total = (uint64_t)c.cx * c.cy, seg_len = (uint64_t)c.rps * c.cy;
     float s = 0.0f;
     for (uint32_t j0 = 0; j0 < c.nseg; j0 += 64) {
-        SegRes mine{};                                                   // lane t holds segment j0 + t
+        // lane t holds segment j0 + t: its exponent, its packed copy, and the sub-block maps under es (a) and es + 1 (b)
+        uint32_t m_es = 0u, m_pack = 0xFFFFFFFFu, ma0[4], ma1[4], mb0[4], mb1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ma0[q] = ma1[q] = mb0[q] = mb1[q] = exact::kCap;
         if (j0 + lane < c.nseg) {
             const SegRes *r = res + j0 + lane;
-            mine.es = load_agent(&r->es); mine.a0 = load_agent(&r->a0); mine.a1 = load_agent(&r->a1); mine.pack = load_agent(&r->pack);
+            m_es = load_agent(&r->es); m_pack = load_agent(&r->pack);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ma0[q] = load_agent(&r->a0[q]); ma1[q] = load_agent(&r->a1[q]); mb0[q] = load_agent(&r->b0[q]); mb1[q] = load_agent(&r->b1[q]); }
         }
         const uint32_t cnt = min(64u, c.nseg - j0);
         for (uint32_t t = 0; t < cnt; ++t) {
-            const uint32_t es_j = (uint32_t)__builtin_amdgcn_readlane((int)mine.es, (int)t);
-            const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)mine.a0, (int)t);
-            const uint32_t a1 = (uint32_t)__builtin_amdgcn_readlane((int)mine.a1, (int)t);
-            const uint32_t sb = __builtin_bit_cast(uint32_t, s);
-            if (es_j != 0u && (sb >> 23) == es_j) {
-                const uint32_t S = (sb & 0x7FFFFFu) | 0x800000u;
-                const uint32_t Sn = S + ((S & 1u) ? a1 : a0);
-                if (Sn < (1u << 24)) { s = __builtin_bit_cast(float, (es_j << 23) | (Sn & 0x7FFFFFu)); continue; }
-            }
-            // re-walk this segment from the true sum: from the packed copy if its wavefront got as far as making one
+            const uint32_t es_j = (uint32_t)__builtin_amdgcn_readlane((int)m_es, (int)t);
+            const uint32_t pack_off = (uint32_t)__builtin_amdgcn_readlane((int)m_pack, (int)t);
             const uint64_t begin = (uint64_t)(j0 + t) * seg_len, end = min<uint64_t>(begin + seg_len, total);
-            const uint32_t pack_off = (uint32_t)__builtin_amdgcn_readlane((int)mine.pack, (int)t);
-            if (pack_off != 0xFFFFFFFFu)                                  // PackedSrc indexes by chain element: rebase to the segment
-                s = exact::ordered_walk<16>(exact::PackedSrc{st.packed + pack_off - begin}, lane, begin, end, s);
-            else
-                s = exact::ordered_walk<16>(chain_src(st, c), lane, begin, end, s);
+            const uint64_t share = (end - begin + 63) / 64;               // as segment_fn dealt the segment to its lanes
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint64_t qb = begin + 16ull * q * share, qe = min<uint64_t>(begin + 16ull * (q + 1) * share, end);
+                if (qb >= end) break;
+                const uint32_t sb = __builtin_bit_cast(uint32_t, s), e = sb >> 23;
+                if (es_j != 0u && (e == es_j || e == es_j + 1u)) {
+                    const bool up = e != es_j;                            // the sum is one binade above the prediction: the es + 1 maps
+                    const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)(up ? mb0[q] : ma0[q]), (int)t);
+                    const uint32_t a1 = (uint32_t)__builtin_amdgcn_readlane((int)(up ? mb1[q] : ma1[q]), (int)t);
+                    const uint32_t S = (sb & 0x7FFFFFu) | 0x800000u;
+                    const uint32_t Sn = S + ((S & 1u) ? a1 : a0);
+                    if (Sn < (1u << 24)) { s = __builtin_bit_cast(float, (e << 23) | (Sn & 0x7FFFFFu)); continue; }
+                }
+                // walk this sub-block from the true sum: from the packed copy if the segment's wavefront made one
+                ++n_rewalk;
+                if (pack_off != 0xFFFFFFFFu)                              // PackedSrc indexes by chain element: rebase to the segment
+                    s = exact::ordered_walk<16>(exact::PackedSrc{st.packed + pack_off - begin}, lane, qb, qe, s);
+                else
+                    s = exact::ordered_walk<16>(chain_src(st, c), lane, qb, qe, s);
+            }
         }
     }
+    if (rewalks) *rewalks = n_rewalk;
     if (lane == 0) finish_chain(st, c, sp, s);
 }
 
@@ -903,13 +939,16 @@ __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
     const uint32_t *list = st.band_items + (uint64_t)xcd * st.band_cap;
     for (uint32_t k = v; k < mine; k += waves_per_xcd) {
         const uint32_t item = list[k];
+        if (st.ablate & 4u) continue;
         const uint32_t w = st.item_chain[item];
         const Chain c = get_chain(st, w, sp);
         const exact::GatherSrc src = chain_src(st, c);
         const uint32_t first = st.item_start[w], j = item - first;
         SegRes *res = st.seg + item;
         const uint32_t pb = __builtin_bit_cast(uint32_t, res->predicted), es = pb >> 23;
-        exact::Fn f{exact::kCap, exact::kCap};
+        exact::BlockMaps maps;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) maps.f[q] = maps.g[q] = exact::Fn{exact::kCap, exact::kCap};
         uint32_t pack_off = 0xFFFFFFFFu;
         if (es >= 1u && es <= 254u && !(st.ablate & 2u)) {
             const uint64_t begin = (uint64_t)j * c.rps * c.cy, end = min<uint64_t>(begin + (uint64_t)c.rps * c.cy, (uint64_t)c.cx * c.cy);
@@ -925,18 +964,16 @@ __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
                 }
                 pack_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)pack_off);
             }
-            f = exact::segment_fn(src, lane, begin, end, es, pack_off != 0xFFFFFFFFu ? st.packed + pack_off : nullptr);
+            maps = exact::segment_fn(src, lane, begin, end, es, pack_off != 0xFFFFFFFFu ? st.packed + pack_off : nullptr);
         }
-        if (st.dbg && lane == 0) {
-            unsigned long long *g = st.dbg + (uint64_t)(*st.n_ops - 1u) * 12;
-            atomicMax(g + 9, (unsigned long long)wall_clock64());         // the last segment map of the merge
-            if (k == 0 && xcd == 0) g[10] = n_items;
-        }
+        if (st.dbg && lane == 0 && k == 0 && xcd == 0) st.dbg[(uint64_t)(*st.n_ops - 1u) * 12 + 10] = n_items;
         uint32_t finished = 0;
-        if (lane == 0) {
-            store_agent(&res->es, (f.a0 >= exact::kCap || f.a1 >= exact::kCap) ? 0u : es);
-            store_agent(&res->a0, f.a0); store_agent(&res->a1, f.a1);
-            store_agent(&res->pack, pack_off);
+        if (lane < 4) {                                                  // lane q publishes sub-block q's maps (uniform values: any lane holds them)
+            uint32_t a0 = maps.f[0].a0, a1 = maps.f[0].a1, b0 = maps.g[0].a0, b1 = maps.g[0].a1;
+#pragma unroll
+            for (int q = 1; q < 4; ++q) if ((int)lane == q) { a0 = maps.f[q].a0; a1 = maps.f[q].a1; b0 = maps.g[q].a0; b1 = maps.g[q].a1; }
+            store_agent(&res->a0[lane], a0); store_agent(&res->a1[lane], a1); store_agent(&res->b0[lane], b0); store_agent(&res->b1[lane], b1);
+            if (lane == 0) { store_agent(&res->es, (es >= 1u && es <= 254u) ? es : 0u); store_agent(&res->pack, pack_off); }
         }
         // this segment's map and packed copy (agent-scope stores of every lane) have been performed ...
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // (a wait for this wavefront's stores; no cache write-back)
@@ -944,9 +981,17 @@ __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
         finished = (uint32_t)__builtin_amdgcn_readfirstlane((int)finished);
         if (finished == c.nseg && !(st.ablate & 1u)) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            commit_chain(st, c, sp, lane, st.seg + first);               // reads the other wavefronts' results with agent-scope loads
+            const unsigned long long t0 = st.dbg ? wall_clock64() : 0ull;
+            uint32_t rw = 0;
+            commit_chain(st, c, sp, lane, st.seg + first, &rw);          // reads the other wavefronts' results with agent-scope loads
+            if (st.dbg && lane == 0) {                                   // tuning aid, stamped by the committing wavefronts only (a few dozen per merge)
+                unsigned long long *g = st.dbg + (uint64_t)(*st.n_ops - 1u) * 12;
+                const unsigned long long t1 = wall_clock64();
+                atomicMax(g + 8, t1);                                    // end of the merge's last commit
+                atomicMax(g + 9, t1 - t0);                               // the longest commit
+                atomicMax(g + 11, ((unsigned long long)c.nseg << 32) | rw);   // ... and the longest chain, in segments, with its re-walks
+            }
         }
-        if (st.dbg && lane == 0) atomicMax(st.dbg + (uint64_t)(*st.n_ops - 1u) * 12 + 8, (unsigned long long)wall_clock64());
     }
 }
 
@@ -1129,6 +1174,8 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return fail(APD_ERR_HIP); }
     // the legacy default stream cannot be captured: then the batch is enqueued directly
+    st.short_chain = kShortChain;
+    if (const char *v = std::getenv("APD_UPGMA_SHORT_CHAIN")) st.short_chain = (uint32_t)std::max(64, std::atoi(v));   // tuning
     if (const char *v = std::getenv("APD_UPGMA_ABLATE")) st.ablate = (uint32_t)std::atoi(v);   // timing-only: results become wrong
     bool use_graph = ctx->stream != nullptr && std::getenv("APD_UPGMA_NO_GRAPH") == nullptr &&   // (the env: plain launches, for profilers that choke on graphs)
                      hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
@@ -1162,7 +1209,7 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     if (st.dbg) {
         std::vector<unsigned long long> g((size_t)n * 12);
         if (hipMemcpy(g.data(), st.dbg, g.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess && cnt > 1) {
-            double ph[4] = {0, 0, 0, 0}, stale = 0, merged = 0, chain = 0, seg = 0, gap = 0, maps = 0, items = 0;
+            double ph[4] = {0, 0, 0, 0}, stale = 0, merged = 0, chain = 0, seg = 0, gap = 0, maps = 0, items = 0, longest = 0, rewalk = 0;
             for (uint32_t t = 1; t + 1 < cnt; ++t) {                      // stamps: 100 MHz; merge 0 scans every row, the last merge ends the loop
                 const unsigned long long *q = &g[(size_t)t * 12];
                 for (int k = 0; k < 4; ++k) ph[k] += (double)(q[k + 1] - q[k]) * 0.01;
@@ -1170,12 +1217,12 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
                 chain += (double)(q[7] - q[4]) * 0.01;                    // end of select's bookkeeping -> last wavefront of the chain launch
                 seg += (double)(std::max(q[8], q[7]) - q[7]) * 0.01;      // -> last wavefront of the segment launch that had work
                 gap += (double)(g[(size_t)(t + 1) * 12] - std::max(q[8], q[7])) * 0.01;
-                if (q[9] > q[7]) { maps += (double)(q[9] - q[7]) * 0.01; items += (double)q[10]; }
+                maps += (double)q[9] * 0.01; items += (double)q[10]; longest += (double)(q[11] >> 32); rewalk += (double)(q[11] & 0xFFFFFFFFull);
             }
             const double m = std::max(1.0, (double)cnt - 2.0);
             std::fprintf(stderr, "[apd] upgma us per merge: select [rows %.2f | arrive %.2f | argmin %.2f | lists %.2f] chain launch %.2f, segment launch %.2f, "
-                                 "(of which until the last segment map %.2f; %.1f segments per merge) to the next select's entry %.2f ; stale rows %.1f, merged list %.1f members\n",
-                         ph[0] / m, ph[1] / m, ph[2] / m, ph[3] / m, chain / m, seg / m, maps / m, items / m, gap / m, stale / m, merged / m);
+                                 "(longest commit %.2f; %.1f segments per merge, longest chain %.1f, %.1f of its sub-blocks walked) to the next select's entry %.2f ; stale rows %.1f, merged list %.1f members\n",
+                         ph[0] / m, ph[1] / m, ph[2] / m, ph[3] / m, chain / m, seg / m, maps / m, items / m, longest / m, rewalk / m, gap / m, stale / m, merged / m);
         }
         hipFree(st.dbg);
     }
