@@ -555,7 +555,8 @@ __device__ float ordered_walk(const Src src, uint32_t lane, uint64_t pos, uint64
         const uint32_t sb = __builtin_bit_cast(uint32_t, s);
         const uint32_t es = sb >> 23;                                   // sign + exponent: 1..254 <=> positive, normal, finite
         const bool fast = es >= 1u && es <= 254u;
-        if ((fast || sb == 0x7F800000u) && total - pos > 64) {          // a remainder of <= 64 elements: one literal round is cheaper
+        const bool tiny = es == 0u;                                     // +0.0 (every chain starts there) or a positive subnormal
+        if ((fast || tiny || sb == 0x7F800000u) && total - pos > 64) {  // a remainder of <= 64 elements: one literal round is cheaper
             float x[kRun];                                              // this lane's run: elements pos + lane * kRun + j
             src.template load_run<kRun>(pos + (uint64_t)lane * kRun, total, x);
             bool bad = false;                                           // negative (incl. -0.0) or NaN: not a map on S
@@ -568,7 +569,7 @@ __device__ float ordered_walk(const Src src, uint32_t lane, uint64_t pos, uint64
             }
             if (bad) f.a0 = f.a1 = kCap;                                // sends the walk into this lane's run, one real add at a time
             const uint64_t step = min<uint64_t>(total - pos, 64ull * kRun);
-            if (!fast) {
+            if (!fast && !tiny) {
                 // s == +INF stays +INF under non-negative finite or infinite terms; a NaN or a negative term (-INF) ends that
                 const unsigned long long bm = __ballot(bad);
                 if (bm == 0ull) { pos += step; continue; }
@@ -578,24 +579,50 @@ __device__ float ordered_walk(const Src src, uint32_t lane, uint64_t pos, uint64
                 pos = min<uint64_t>(pos + (uint64_t)(L + 1) * kRun, total);
                 continue;
             }
-            const Fn pre = wave_scan(f);
-            const uint32_t S = (sb & 0x7FFFFFu) | 0x800000u;
-            const uint32_t adv = (S & 1u) ? pre.a1 : pre.a0;            // S advances by this much up to and including this lane
-            const unsigned long long leaves = __ballot(S + adv >= (1u << 24));
-            if (leaves == 0ull) {
-                const uint32_t Sn = S + (uint32_t)__builtin_amdgcn_readlane((int)adv, 63);
-                s = __builtin_bit_cast(float, (es << 23) | (Sn & 0x7FFFFFu));
-                pos += step;
-                continue;
-            }
-            const int L = __builtin_ctzll(leaves);                      // first lane whose run takes the sum out of the binade
-            if (L > 0) {
-                const uint32_t Sn = S + (uint32_t)__builtin_amdgcn_readlane((int)adv, L - 1);
-                s = __builtin_bit_cast(float, (es << 23) | (Sn & 0x7FFFFFu));
-            }
+            // The loaded elements stay in registers while the sum climbs through binades: a lane whose run takes the sum out of its
+            // binade is added with real f32 adds, and the lanes behind it are re-mapped under the new exponent and scanned again --
+            // no reload.  (A sum that starts at zero changes binade ten times inside its first thousand elements: reloading after
+            // each change made a short chain a dozen dependent memory round trips long.)
+            uint32_t start = 0;                                          // lanes below `start` are consumed
+            for (;;) {
+                const uint32_t sb2 = __builtin_bit_cast(uint32_t, s), es2 = sb2 >> 23;
+                if (es2 == 0u) {                                         // no integer map on a zero / subnormal sum: this lane's run by real adds,
+                    const int L0 = (int)start;                           // then on with the lanes behind it -- a chain's start costs no load of its own
 #pragma unroll
-            for (int j = 0; j < kRun; ++j) s = s + readlane_f(x[j], L);  // real adds: any rounding regime, any jump
-            pos = min<uint64_t>(pos + (uint64_t)(L + 1) * kRun, total);
+                    for (int j = 0; j < kRun; ++j) s = s + readlane_f(x[j], L0);
+                    if (++start >= 64u) break;
+                    continue;
+                }
+                if (es2 > 254u) break;                                   // negative, +INF or NaN now: the outer loop's other paths
+                if (start != 0u) {                                       // re-map under the current exponent, consumed lanes as the identity
+                    f = Fn{0u, 0u};
+                    if (lane >= start) {
+#pragma unroll
+                        for (int j = 0; j < kRun; ++j) f = compose(f, element(__builtin_bit_cast(uint32_t, x[j]), es2));
+                        if (bad) f.a0 = f.a1 = kCap;
+                    }
+                }
+                const Fn pre = wave_scan(f);
+                const uint32_t S = (sb2 & 0x7FFFFFu) | 0x800000u;
+                const uint32_t adv = (S & 1u) ? pre.a1 : pre.a0;        // S advances by this much up to and including this lane
+                const unsigned long long leaves = __ballot(S + adv >= (1u << 24));
+                if (leaves == 0ull) {
+                    const uint32_t Sn = S + (uint32_t)__builtin_amdgcn_readlane((int)adv, 63);
+                    s = __builtin_bit_cast(float, (es2 << 23) | (Sn & 0x7FFFFFu));
+                    start = 64u;
+                    break;
+                }
+                const int L = __builtin_ctzll(leaves);                  // first lane whose run takes the sum out of the binade (>= start)
+                if (L > 0 && (uint32_t)L > start) {
+                    const uint32_t Sn = S + (uint32_t)__builtin_amdgcn_readlane((int)adv, L - 1);
+                    s = __builtin_bit_cast(float, (es2 << 23) | (Sn & 0x7FFFFFu));
+                }
+#pragma unroll
+                for (int j = 0; j < kRun; ++j) s = s + readlane_f(x[j], L);  // real adds: any rounding regime, any jump
+                start = (uint32_t)L + 1u;
+                if (start >= 64u) break;
+            }
+            pos = min<uint64_t>(pos + (uint64_t)start * kRun, total);
         } else {
             // literal path (s is zero, subnormal, negative or NaN, or the chain is about to end): 64 elements, one real add each
             const uint64_t e = pos + lane;
@@ -916,9 +943,9 @@ __device__ void commit_chain(const UpgmaState &st, const Chain &c, uint32_t sp, 
                 // walk this sub-block from the true sum: from the packed copy if the segment's wavefront made one
                 ++n_rewalk;
                 if (pack_off != 0xFFFFFFFFu)                              // PackedSrc indexes by chain element: rebase to the segment
-                    s = exact::ordered_walk<16>(exact::PackedSrc{st.packed + pack_off - begin}, lane, qb, qe, s);
+                    s = exact::ordered_walk<8>(exact::PackedSrc{st.packed + pack_off - begin}, lane, qb, qe, s);   // (16 per lane: the kernel spills)
                 else
-                    s = exact::ordered_walk<16>(chain_src(st, c), lane, qb, qe, s);
+                    s = exact::ordered_walk<8>(chain_src(st, c), lane, qb, qe, s);
             }
         }
     }

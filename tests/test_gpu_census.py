@@ -139,3 +139,15 @@ def test_strict_bitwise_and_default_known_deviation_bound_cfg5_shape_from_device
     max_rel, over, worst, counted = census(default, strict)
     assert counted == n * (n - 1)                                       # 16 distinct recordings and noisy takes of them: no exact repeat
     assert_known_deviation_bound("cfg5 shape", max_rel, over, worst)
+
+
+def test_strict_mode_is_bitwise_the_oracle_on_every_entry_of_cfg2(ctx, apd, oracle):
+    """Not a sample: all 1 047 552 ordered pairs of the cfg 2 corpus, strict mode against the CPU oracle, bit for bit (the oracle
+    needs ~15 s for them on 16 threads).  The same comparison over all 16.8 M pairs of cfg 3 takes the oracle 13 minutes:
+    tools/strict_full_check.py, result in profiles/r04/strict_full_matrix_cfg3.txt."""
+    n = 1024
+    frames, offsets = synth.make_sequences(n, 512, 13, seed=0xA9D2)
+    _, strict = both_modes(apd, ctx, ctx.upload(frames), offsets, 13, 0.0625)
+    want = oracle.align_all(frames, offsets, 0.0625, workers=16)
+    differing = int((strict.view(np.uint32) != want.view(np.uint32)).sum())
+    assert differing == 0, "%d of %d entries differ bitwise" % (differing, n * n)
