@@ -192,7 +192,7 @@ struct UpgmaState {
     uint32_t *band_count;
     uint32_t band_cap;
     uint32_t short_chain;     // chains up to this many elements are walked whole by one wavefront
-    uint32_t ablate;          // timing-only experiments (results wrong): 1 no commit, 2 no segment maps, 4 no segment work at all, 8 no predict
+    uint32_t ablate;          // timing-only experiments (results wrong): 1 no commit, 2 no segment maps, 4 no segment work at all, 8 no predict; 16 = round-robin XCD lists (results right)
     uint32_t *seg_done;       // [2 n] finished segments of a segmented chain
     float *packed;            // contiguous copies of the segments the commit pass is likely to re-walk (nullptr: off)
     uint32_t *pack_used;      // bump allocator of `packed`, reset per merge
@@ -201,7 +201,7 @@ struct UpgmaState {
     SegRes *seg;              // [max_items] segment results of the current merge
     uint32_t *n_items;
     uint32_t *done;           // set once the loop condition of clustering.rs:104 fails
-    unsigned long long *dbg;  // APD_DEBUG_UPGMA_TIMING: [n][12] wall_clock64 stamps per merge (nullptr: off)
+    unsigned long long *dbg;  // APD_DEBUG_UPGMA_TIMING: [n][16] wall_clock64 stamps per merge (nullptr: off)
     float threshold;
     uint32_t n;
 };
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
     }
     if (threadIdx.x == 0) {
         if (st.dbg) {
-            unsigned long long *g = st.dbg + (uint64_t)t * 12;
+            unsigned long long *g = st.dbg + (uint64_t)t * 16;
             g[0] = t_entry; g[1] = t_rows; g[2] = t_last; g[3] = t_argmin; g[4] = wall_clock64(); g[5] = ns; g[6] = cp + cq;
         }
         uint32_t op;
@@ -518,12 +518,22 @@ struct GatherSrc {
             if (total <= 0xFFFFFFFFull) { a = (uint32_t)first / cy; b = (uint32_t)first - a * cy; }          // wave-uniform: the cheap division
             else { a = (uint32_t)(first / cy); b = (uint32_t)(first - (uint64_t)a * cy); }
         }
-        const float *row = m + (uint64_t)lx[min(a, cx - 1)] * sx;
+        // Indices first (no memory), then every list entry, then every element: TWO dependent round trips per run whatever cy is.
+        // (Written with a branch per element -- "next row?" -- the compiler waits for each load before the next: sixteen trips.)
+        uint32_t aa[K], bb[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const bool live = first + j < total;
-            x[j] = live ? row[(uint64_t)ly[b] * sy] : 0.0f;             // padding: +0.0 is the identity
-            if (live && ++b == cy) { b = 0; ++a; row = m + (uint64_t)lx[min(a, cx - 1)] * sx; }
+            aa[j] = min(a, cx - 1); bb[j] = b;                          // b < cy always; a runs past cx - 1 only behind `total`
+            const bool wrap = ++b == cy;
+            b = wrap ? 0u : b; a += wrap ? 1u : 0u;
+        }
+        uint32_t ra[K], cb[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) { ra[j] = lx[aa[j]]; cb[j] = ly[bb[j]]; }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const float v = m[(uint64_t)ra[j] * sx + (uint64_t)cb[j] * sy];
+            x[j] = first + j < total ? v : 0.0f;                        // padding: +0.0 is the identity
         }
     }
     __device__ __forceinline__ float load_one(uint64_t e, uint64_t total) const
@@ -540,7 +550,10 @@ struct PackedSrc {
     __device__ __forceinline__ void load_run(uint64_t first, uint64_t total, float (&x)[K]) const
     {
 #pragma unroll
-        for (int j = 0; j < K; ++j) x[j] = first + j < total ? load_agent(p + first + j) : 0.0f;   // written by another wavefront of this launch
+        for (int j = 0; j < K; ++j) {                                   // written by another wavefront of this launch; branch-free, so the K loads
+            const float v = load_agent(p + min<uint64_t>(first + j, total - 1));   // are in flight together (total >= 1 wherever a walk runs)
+            x[j] = first + j < total ? v : 0.0f;
+        }
     }
     __device__ __forceinline__ float load_one(uint64_t e, uint64_t) const { return load_agent(p + e); }
 };
@@ -809,7 +822,7 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
     const uint32_t nl = *st.n_live;
     const uint32_t group_waves = 2u * ((st.n + 63u) / 64u);
     auto stamp = [&]() __attribute__((always_inline)) {                  // tuning aid: when the last wavefront with work finished
-        if (st.dbg && lane == 0) atomicMax(st.dbg + (uint64_t)(*st.n_ops - 1u) * 12 + 7, (unsigned long long)wall_clock64());
+        if (st.dbg && lane == 0) atomicMax(st.dbg + (uint64_t)(*st.n_ops - 1u) * 16 + 7, (unsigned long long)wall_clock64());
     };
     if (wid < group_waves) {
         const uint32_t dir = wid & 1u, cidx = (wid >> 1) * 64u + lane;
@@ -880,17 +893,17 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
     uint32_t base = 0;
     if (lane == 0) { base = atomicAdd(st.n_items, c.nseg); st.item_start[w] = base; st.seg_done[w] = 0u; }
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    // Every segment also goes onto the work list of ONE XCD, chosen by where in the source matrix it reads: a dir-0 chain reads the
-    // rows of d that belong to the new cluster -- band = (first row of the segment) * 8 / |Ck|; a dir-1 chain reads ALL of those rows
-    // of the transposed copy at the columns of its own members -- band = (first column) * 8 / n.  The segments of different chains
-    // interleave inside those rows (every cache line of a row holds columns of several clusters), and gathering them is bound by
-    // miss latency x outstanding requests: with one eighth of the K x n source per XCD (3.4 MB at K = 424, n = 16384) the lines a
-    // segment needs have usually been brought into that XCD's L2 by a neighbour.  A locality hint only: any assignment is correct.
+    // Every segment goes onto the work list of ONE XCD (blocks b and b + 8 of launch 3 share an XCD), chosen by where in the source
+    // matrix it reads: a dir-0 chain reads the rows of d that belong to the new cluster -- band = (first row of the segment) * 8 /
+    // |Ck|; a dir-1 chain reads those rows of the transposed copy at the columns of its own members -- band = (first column) * 8 / n.
+    // A locality hint only, any assignment is correct -- and a measured non-effect (round 4, same box, APD_UPGMA_ABLATE=16 deals the
+    // items round robin instead: chain proxy 5.68 vs 5.61 s, 16384-blob 0.892 vs 0.908 s): the gathers are not what launch 3 waits for.
     if (st.ablate & 8u) return;
     for (uint32_t j = lane; j < c.nseg; j += 64) {
         st.item_chain[base + j] = w;
         const uint32_t a0 = j * c.rps;
-        const uint32_t band = c.dir == 0u ? (uint32_t)(((uint64_t)a0 * 8u) / c.cx) : (uint32_t)(((uint64_t)c.lx[a0] * 8u) / st.n);
+        uint32_t band = c.dir == 0u ? (uint32_t)(((uint64_t)a0 * 8u) / c.cx) : (uint32_t)(((uint64_t)c.lx[a0] * 8u) / st.n);
+        if (st.ablate & 16u) band = (base + j) & 7u;                     // A/B: round robin (results stay right)
         st.band_items[(uint64_t)min(band, 7u) * st.band_cap + atomicAdd(&st.band_count[min(band, 7u)], 1u)] = base + j;
     }
     predict_chain(st, c, sp, lane, st.seg + base);
@@ -898,10 +911,9 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
 }
 
 // Launch 3 of a merge: the segments of the long chains.  A segment gets its integer map under the predicted exponent
-// (exact::segment_fn).  Items are dealt to wavefronts in groups of 32 consecutive items per XCD (blocks b and b + 8 share an XCD
-// and its L2): neighbouring segments read neighbouring rows, so a line comes in from HBM / Infinity Cache once per group instead
-// of once per XCD.  (Placement is a speed matter only.)  A segment is also copied to `packed`, contiguously, when the commit is
-// likely to re-walk it: the predicted sum changes binade inside it or sits within 2^-10 of a power of two.
+// (exact::segment_fn).  The wavefronts of an XCD take the items of that XCD's work list (filled by launch 2) in turn.  A segment is
+// also copied to `packed`, contiguously, when the commit is likely to re-walk it: the predicted sum changes binade inside it or
+// sits within 2^-10 of a power of two.
 // The wavefront that finishes the LAST segment of a chain (atomic counter behind a fence) commits the chain: the true sum through
 // the segments, in order -- a segment whose assumed exponent matches and whose map keeps the sum inside the binade is applied in
 // O(1), any other one is re-walked element by element from the true sum.
@@ -993,7 +1005,7 @@ __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
             }
             maps = exact::segment_fn(src, lane, begin, end, es, pack_off != 0xFFFFFFFFu ? st.packed + pack_off : nullptr);
         }
-        if (st.dbg && lane == 0 && k == 0 && xcd == 0) st.dbg[(uint64_t)(*st.n_ops - 1u) * 12 + 10] = n_items;
+        if (st.dbg && lane == 0 && k == 0 && xcd == 0) st.dbg[(uint64_t)(*st.n_ops - 1u) * 16 + 10] = n_items;
         uint32_t finished = 0;
         if (lane < 4) {                                                  // lane q publishes sub-block q's maps (uniform values: any lane holds them)
             uint32_t a0 = maps.f[0].a0, a1 = maps.f[0].a1, b0 = maps.g[0].a0, b1 = maps.g[0].a1;
@@ -1012,11 +1024,13 @@ __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
             uint32_t rw = 0;
             commit_chain(st, c, sp, lane, st.seg + first, &rw);          // reads the other wavefronts' results with agent-scope loads
             if (st.dbg && lane == 0) {                                   // tuning aid, stamped by the committing wavefronts only (a few dozen per merge)
-                unsigned long long *g = st.dbg + (uint64_t)(*st.n_ops - 1u) * 12;
+                unsigned long long *g = st.dbg + (uint64_t)(*st.n_ops - 1u) * 16;
                 const unsigned long long t1 = wall_clock64();
                 atomicMax(g + 8, t1);                                    // end of the merge's last commit
                 atomicMax(g + 9, t1 - t0);                               // the longest commit
                 atomicMax(g + 11, ((unsigned long long)c.nseg << 32) | rw);   // ... and the longest chain, in segments, with its re-walks
+                atomicMax(g + 12, t0);                                   // the start of the last commit to start
+                atomicAdd(g + 13, t1 - t0); atomicAdd(g + 14, 1ull); atomicAdd(g + 15, (unsigned long long)rw);
             }
         }
     }
@@ -1186,8 +1200,8 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     // one wavefront per item up to 32768 items (a wavefront that commits a chain must not hold other items back), grid-stride beyond
     const uint32_t segment_blocks = (std::min((2 * n + 3) / 4, 8192u) + 63u) / 64u * 64u;   // groups of 32 wavefronts per XCD
     const bool debug_timing = std::getenv("APD_DEBUG_UPGMA_TIMING") != nullptr;   // tuning aid: phase stamps of every select launch
-    if (debug_timing && hipMalloc((void **)&st.dbg, (size_t)n * 12 * sizeof(unsigned long long)) == hipSuccess)
-        (void)hipMemsetAsync(st.dbg, 0, (size_t)n * 12 * sizeof(unsigned long long), ctx->stream);
+    if (debug_timing && hipMalloc((void **)&st.dbg, (size_t)n * 16 * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemsetAsync(st.dbg, 0, (size_t)n * 16 * sizeof(unsigned long long), ctx->stream);
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     auto enqueue_batch = [&]() {
@@ -1234,22 +1248,26 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     drop_graph();
     const uint32_t cnt = host_state[1];
     if (st.dbg) {
-        std::vector<unsigned long long> g((size_t)n * 12);
+        std::vector<unsigned long long> g((size_t)n * 16);
         if (hipMemcpy(g.data(), st.dbg, g.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess && cnt > 1) {
-            double ph[4] = {0, 0, 0, 0}, stale = 0, merged = 0, chain = 0, seg = 0, gap = 0, maps = 0, items = 0, longest = 0, rewalk = 0;
+            double ph[4] = {0, 0, 0, 0}, stale = 0, merged = 0, chain = 0, seg = 0, gap = 0, maps = 0, items = 0, longest = 0, rewalk = 0, cstart = 0, csum = 0, ccnt = 0, rwsum = 0;
             for (uint32_t t = 1; t + 1 < cnt; ++t) {                      // stamps: 100 MHz; merge 0 scans every row, the last merge ends the loop
-                const unsigned long long *q = &g[(size_t)t * 12];
+                const unsigned long long *q = &g[(size_t)t * 16];
                 for (int k = 0; k < 4; ++k) ph[k] += (double)(q[k + 1] - q[k]) * 0.01;
                 stale += (double)q[5]; merged += (double)q[6];
                 chain += (double)(q[7] - q[4]) * 0.01;                    // end of select's bookkeeping -> last wavefront of the chain launch
                 seg += (double)(std::max(q[8], q[7]) - q[7]) * 0.01;      // -> last wavefront of the segment launch that had work
-                gap += (double)(g[(size_t)(t + 1) * 12] - std::max(q[8], q[7])) * 0.01;
+                gap += (double)(g[(size_t)(t + 1) * 16] - std::max(q[8], q[7])) * 0.01;
                 maps += (double)q[9] * 0.01; items += (double)q[10]; longest += (double)(q[11] >> 32); rewalk += (double)(q[11] & 0xFFFFFFFFull);
+                if (q[12] > q[7]) cstart += (double)(q[12] - q[7]) * 0.01;
+                csum += (double)q[13] * 0.01; ccnt += (double)q[14]; rwsum += (double)q[15];
             }
             const double m = std::max(1.0, (double)cnt - 2.0);
             std::fprintf(stderr, "[apd] upgma us per merge: select [rows %.2f | arrive %.2f | argmin %.2f | lists %.2f] chain launch %.2f, segment launch %.2f, "
                                  "(longest commit %.2f; %.1f segments per merge, longest chain %.1f, %.1f of its sub-blocks walked) to the next select's entry %.2f ; stale rows %.1f, merged list %.1f members\n",
                          ph[0] / m, ph[1] / m, ph[2] / m, ph[3] / m, chain / m, seg / m, maps / m, items / m, longest / m, rewalk / m, gap / m, stale / m, merged / m);
+            std::fprintf(stderr, "[apd] upgma commits: %.1f per merge, mean %.2f us each, %.2f sub-block walks each; the last one starts %.2f us after the chain launch's end\n",
+                         ccnt / m, csum / std::max(1.0, ccnt), rwsum / std::max(1.0, ccnt), cstart / m);
         }
         hipFree(st.dbg);
     }
