@@ -135,7 +135,7 @@ struct Cand { float l; uint32_t idp, idq, sp, sq; };
 // map S -> S + (S odd ? a1 : a0) under es (a0 / a1) and under es + 1 (b0 / b1): when the running sum changes binade inside the
 // segment, the commit walks the one sub-block that holds the change and goes on with the es + 1 maps -- a quarter of a segment
 // re-walked per binade change instead of the whole of it.  A map that cannot be used holds kCap.
-struct SegRes { float predicted; uint32_t es, pack, pad; uint32_t a0[4], a1[4], b0[4], b1[4]; };   // pack: offset of the segment's contiguous copy, or ~0
+struct SegRes { float predicted; uint32_t es, pack, pad; uint32_t a0[4], a1[4], b0[4], b1[4]; };   // pack: offset of the segment's contiguous copy, or ~0; pad: see kExactSegment
 
 __device__ __forceinline__ bool better(const Cand &a, const Cand &b)
 {
@@ -161,7 +161,12 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
 }
 
 struct UpgmaState {
-    const float *d;           // [n][n] raw distances (read only)
+    const float *d;           // [n][n] raw distances as the caller laid them out (read only): threshold and the initial S
+    const float *const *mat;  // device words: [0] the WORKING copy of d, [1] of its transpose -- rows and columns in `phys` order (the caller's
+                              // order until the first defragmentation, see upgma_permute_kernel); [2] non-null once defragmented
+    uint32_t *ppool;          // the member lists again, same offsets as `pool`, as PHYSICAL rows / columns of the working copies
+    uint32_t *phys;           // [n] instance -> its physical row / column
+    uint32_t *dsrc, *doff;    // [n] defragmentation scratch: new physical index -> old one; first new index of the i-th live cluster
     float *S;                 // [n][n] directed cluster sums (slot-indexed)
     uint32_t *pool;           // sorted member lists, appended per merge
     uint32_t *mstart, *mcount;// [n] list of the cluster held by a slot
@@ -185,6 +190,7 @@ struct UpgmaState {
     uint32_t *last_sq;        // slot that died in the latest merge
     apd_cluster_op *ops;      // [n]
     uint32_t *n_ops;
+    uint32_t *work;           // sum of the new clusters' member counts so far (wraps; the host looks at differences): when to defragment
     float *R;                 // [n][n] R[x][slot]: approximate sum of d[x][y] over the members y of the cluster in `slot`
     uint32_t *item_start;     // [2 n] first work item (segment) of a segmented chain of the current merge
     uint32_t *item_chain;     // [max_items] chain of every work item
@@ -197,7 +203,6 @@ struct UpgmaState {
     float *packed;            // contiguous copies of the segments the commit pass is likely to re-walk (nullptr: off)
     uint32_t *pack_used;      // bump allocator of `packed`, reset per merge
     uint32_t pack_capacity;   // floats
-    const float *dT;          // [n][n] transposed copy of d (nullptr: off)
     SegRes *seg;              // [max_items] segment results of the current merge
     uint32_t *n_items;
     uint32_t *done;           // set once the loop condition of clustering.rs:104 fails
@@ -382,15 +387,15 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
     const uint32_t at = st.pos[w.sq], tail = st.live[nl - 1];
     // merge the two sorted member lists into a fresh one
     {
-        const uint32_t *lp = st.pool + msp, *lq = st.pool + msq;
-        uint32_t *out = st.pool + used;
+        const uint32_t *lp = st.pool + msp, *lq = st.pool + msq, *pp = st.ppool + msp, *pq = st.ppool + msq;
+        uint32_t *out = st.pool + used, *pout = st.ppool + used;          // the order is decided by the instance numbers; the physical list follows
         for (uint32_t i = threadIdx.x; i < cp + cq; i += blockDim.x) {
             const bool from_p = i < cp;
-            const uint32_t v = from_p ? lp[i] : lq[i - cp];
+            const uint32_t v = from_p ? lp[i] : lq[i - cp], pv = from_p ? pp[i] : pq[i - cp];
             const uint32_t *other = from_p ? lq : lp;
             uint32_t lo = 0, hi = from_p ? cq : cp;                       // members are distinct: plain lower bound
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (other[mid] < v) lo = mid + 1; else hi = mid; }
-            out[(from_p ? i : i - cp) + lo] = v;
+            out[(from_p ? i : i - cp) + lo] = v; pout[(from_p ? i : i - cp) + lo] = pv;
         }
     }
     if (threadIdx.x == 0) {
@@ -405,6 +410,7 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
         else op = APD_SEQUENCE2CLUSTER;
         st.ops[t] = apd_cluster_op{w.idp, w.idq, k, w.l, op};
         *st.n_ops = t + 1;
+        *st.work += cp + cq;
         st.size[w.sp] = zp + zq;
         st.size[w.sq] = 0.0f;                                             // dead: skipped by every scan
         st.rb_l[w.sq] = __builtin_inff();
@@ -724,7 +730,8 @@ constexpr uint32_t kLaneChain = 2048;            // a SINGLETON against a new cl
 
 
 struct Chain {
-    const uint32_t *lx, *ly;
+    const uint32_t *lx, *ly;  // members as instance numbers (rows of R); plx / ply: the same members as physical rows / columns
+    const uint32_t *plx, *ply;
     uint32_t cx, cy;
     uint32_t slot_y;        // slot of the cluster the inner index runs over (its column of R predicts the row sums)
     uint32_t s, dir;        // the other cluster's slot; dir 0: S[sp][s], dir 1: S[s][sp]
@@ -740,7 +747,8 @@ __device__ __forceinline__ Chain get_chain(const UpgmaState &st, uint32_t w, uin
     c.s = w >> 1;
     if (c.s == sp) return c;                                             // nseg = 0
     const uint32_t sx = c.dir ? c.s : sp, sy = c.dir ? sp : c.s;
-    c.lx = st.pool + st.mstart[sx]; c.ly = st.pool + st.mstart[sy];
+    const uint32_t mx = st.mstart[sx], my = st.mstart[sy];
+    c.lx = st.pool + mx; c.ly = st.pool + my; c.plx = st.ppool + mx; c.ply = st.ppool + my;
     c.cx = st.mcount[sx]; c.cy = st.mcount[sy];
     c.slot_y = sy;
     const uint64_t len = (uint64_t)c.cx * c.cy;
@@ -751,13 +759,15 @@ __device__ __forceinline__ Chain get_chain(const UpgmaState &st, uint32_t w, uin
     return c;
 }
 
-// S[sp][s] chains (dir 0) walk rows of d; S[s][sp] chains (dir 1) would walk columns of d restricted to the new cluster --
-// one float per cache line, lines that no other chain uses.  They read the transposed copy instead, where the same
-// elements lie in the new cluster's |Ck| rows: the chains of neighbouring clusters then share cache lines in both directions.
+// S[sp][s] chains (dir 0) walk rows of d.  S[s][sp] chains (dir 1) walk, in the caller's layout, columns of d restricted to the new
+// cluster -- one float per cache line, lines that no other chain uses -- so they read the transposed copy there, where the same
+// elements lie in the new cluster's |Ck| rows.  Once the working copies are DEFRAGMENTED (a cluster's members are neighbouring
+// rows and columns, upgma_permute_kernel) the inner index of both directions runs along a row of d and dir 1 reads d as well.
 __device__ __forceinline__ exact::GatherSrc chain_src(const UpgmaState &st, const Chain &c)
 {
-    if (c.dir == 0 || st.dT == nullptr) return exact::GatherSrc{st.d, st.n, 1, c.lx, c.cx, c.ly, c.cy};
-    return exact::GatherSrc{st.dT, 1, st.n, c.lx, c.cx, c.ly, c.cy};
+    const float *d = st.mat[0], *dT = st.mat[1];
+    if (c.dir == 0 || st.mat[2] != nullptr) return exact::GatherSrc{d, st.n, 1, c.plx, c.cx, c.ply, c.cy};
+    return exact::GatherSrc{dT, 1, st.n, c.plx, c.cx, c.ply, c.cy};
 }
 
 // what lane 0 does with a finished sum (the tail of the former one-kernel update)
@@ -833,12 +843,11 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
         const uint32_t own = cidx < nl ? st.live[cidx] : sp;
         const bool active = own != sp && K <= kLaneChain && st.mcount[own] == 1u;
         if (__ballot(active) == 0ull) return;
-        // element i is M[ck[i] * rs + own * cs]
-        const uint32_t *ck = st.pool + ms;                              // wave-uniform
-        const bool transposed = dir == 1 && st.dT != nullptr;
-        const float *M = transposed ? st.dT : st.d;
-        const uint64_t rs = (dir == 1 && !transposed) ? 1 : st.n, cs = (dir == 1 && !transposed) ? st.n : 1;
-        const uint64_t col = active ? (uint64_t)own * cs : 0;
+        // element i is M[ck[i] * n + phys[own]]
+        const uint32_t *ck = st.ppool + ms;                             // wave-uniform (physical rows)
+        const float *M = st.mat[dir];                                   // dir 1: the transposed copy
+        const uint64_t rs = st.n;
+        const uint64_t col = active ? (uint64_t)st.phys[own] : 0;
         // what the end of the chain needs (the row's cached best pair, the sizes and ids of its candidate), requested before the
         // sum's own loads instead of after them: one memory round trip less on the launch's critical path
         Cand old{};
@@ -902,7 +911,7 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
     for (uint32_t j = lane; j < c.nseg; j += 64) {
         st.item_chain[base + j] = w;
         const uint32_t a0 = j * c.rps;
-        uint32_t band = c.dir == 0u ? (uint32_t)(((uint64_t)a0 * 8u) / c.cx) : (uint32_t)(((uint64_t)c.lx[a0] * 8u) / st.n);
+        uint32_t band = c.dir == 0u ? (uint32_t)(((uint64_t)a0 * 8u) / c.cx) : (uint32_t)(((uint64_t)c.plx[a0] * 8u) / st.n);
         if (st.ablate & 16u) band = (base + j) & 7u;                     // A/B: round robin (results stay right)
         st.band_items[(uint64_t)min(band, 7u) * st.band_cap + atomicAdd(&st.band_count[min(band, 7u)], 1u)] = base + j;
     }
@@ -915,8 +924,15 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
 // also copied to `packed`, contiguously, when the commit is likely to re-walk it: the predicted sum changes binade inside it or
 // sits within 2^-10 of a power of two.
 // The wavefront that finishes the LAST segment of a chain (atomic counter behind a fence) commits the chain: the true sum through
-// the segments, in order -- a segment whose assumed exponent matches and whose map keeps the sum inside the binade is applied in
-// O(1), any other one is re-walked element by element from the true sum.
+// the segments, in order.  The segments' maps are themselves composed by a 64-lane prefix scan (lane t = segment j0 + t, each under
+// the map that fits the sum's current binade: its es map, its es + 1 map, or none): one scan carries the sum up to the first segment
+// whose map does not keep it inside the binade -- a change of binade, or a misprediction -- and only THAT segment is taken apart:
+// its four sub-block maps one by one, the sub-block that holds the change walked element by element (from the packed copy if the
+// segment's wavefront made one); then the scan resumes behind it under the new exponent.  A chain of 71 segments changes binade
+// five or six times behind its first segment: six scans and six walked sub-blocks instead of 284 dependent map applications.
+// The FIRST segment starts from +0.0 exactly, so its wavefront has already walked it for real: kExactSegment, the sum in `pad`.
+constexpr uint32_t kExactSegment = 0xFFFFFFFFu;
+
 __device__ void commit_chain(const UpgmaState &st, const Chain &c, uint32_t sp, uint32_t lane, const SegRes *res, uint32_t *rewalks = nullptr)
 {
     uint32_t n_rewalk = 0;
@@ -924,41 +940,77 @@ __device__ void commit_chain(const UpgmaState &st, const Chain &c, uint32_t sp, 
     float s = 0.0f;
     for (uint32_t j0 = 0; j0 < c.nseg; j0 += 64) {
         // lane t holds segment j0 + t: its exponent, its packed copy, and the sub-block maps under es (a) and es + 1 (b)
-        uint32_t m_es = 0u, m_pack = 0xFFFFFFFFu, ma0[4], ma1[4], mb0[4], mb1[4];
+        uint32_t m_es = 0u, m_pack = 0xFFFFFFFFu, m_exact = 0u, ma0[4], ma1[4], mb0[4], mb1[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) ma0[q] = ma1[q] = mb0[q] = mb1[q] = exact::kCap;
         if (j0 + lane < c.nseg) {
             const SegRes *r = res + j0 + lane;
-            m_es = load_agent(&r->es); m_pack = load_agent(&r->pack);
+            m_es = load_agent(&r->es); m_pack = load_agent(&r->pack); m_exact = load_agent(&r->pad);
 #pragma unroll
             for (int q = 0; q < 4; ++q) { ma0[q] = load_agent(&r->a0[q]); ma1[q] = load_agent(&r->a1[q]); mb0[q] = load_agent(&r->b0[q]); mb1[q] = load_agent(&r->b1[q]); }
         }
         const uint32_t cnt = min(64u, c.nseg - j0);
-        for (uint32_t t = 0; t < cnt; ++t) {
-            const uint32_t es_j = (uint32_t)__builtin_amdgcn_readlane((int)m_es, (int)t);
-            const uint32_t pack_off = (uint32_t)__builtin_amdgcn_readlane((int)m_pack, (int)t);
-            const uint64_t begin = (uint64_t)(j0 + t) * seg_len, end = min<uint64_t>(begin + seg_len, total);
+        // the whole-segment maps: the four sub-blocks composed, in order (kCap saturates: an unusable sub-block makes an unusable segment)
+        exact::Fn F{ma0[0], ma1[0]}, G{mb0[0], mb1[0]};
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            // (a sub-block behind the end of a short last segment holds the identity)
+            F = exact::compose(F, exact::Fn{ma0[q], ma1[q]}); G = exact::compose(G, exact::Fn{mb0[q], mb1[q]});
+        }
+        uint32_t t = 0;
+        while (t < cnt) {
+            const uint32_t sb = __builtin_bit_cast(uint32_t, s), e = sb >> 23;
+            // lanes [t, cnt): the map that fits the current binade; consumed lanes and lanes behind the chain's end: the identity
+            exact::Fn h{0u, 0u};
+            if (lane >= t && lane < cnt) {
+                const bool usable = m_es >= 1u && m_es <= 254u && e >= 1u && e <= 254u;
+                h = (usable && e == m_es) ? F : (usable && e == m_es + 1u) ? G : exact::Fn{exact::kCap, exact::kCap};
+            }
+            const exact::Fn pre = exact::wave_scan(h);
+            const uint32_t S = (sb & 0x7FFFFFu) | 0x800000u;
+            const uint32_t adv = (S & 1u) ? pre.a1 : pre.a0;
+            const unsigned long long leaves = __ballot(S + adv >= (1u << 24));
+            if (leaves == 0ull) {                                         // (e is normal here: a zero / subnormal / non-finite sum makes every map kCap)
+                const uint32_t Sn = S + (uint32_t)__builtin_amdgcn_readlane((int)adv, 63);
+                s = __builtin_bit_cast(float, (e << 23) | (Sn & 0x7FFFFFu));
+                break;
+            }
+            const uint32_t L = (uint32_t)__builtin_ctzll(leaves);         // >= t: the consumed lanes hold the identity
+            if (L > t) {
+                const uint32_t Sn = S + (uint32_t)__builtin_amdgcn_readlane((int)adv, (int)L - 1);
+                s = __builtin_bit_cast(float, (e << 23) | (Sn & 0x7FFFFFu));
+            }
+            // ---- segment j0 + L taken apart
+            const uint32_t es_j = (uint32_t)__builtin_amdgcn_readlane((int)m_es, (int)L);
+            if (es_j == kExactSegment) {                                  // walked for real by its own wavefront (the chain's first segment)
+                s = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_readlane((int)m_exact, (int)L));
+                t = L + 1u;
+                continue;
+            }
+            const uint32_t pack_off = (uint32_t)__builtin_amdgcn_readlane((int)m_pack, (int)L);
+            const uint64_t begin = (uint64_t)(j0 + L) * seg_len, end = min<uint64_t>(begin + seg_len, total);
             const uint64_t share = (end - begin + 63) / 64;               // as segment_fn dealt the segment to its lanes
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint64_t qb = begin + 16ull * q * share, qe = min<uint64_t>(begin + 16ull * (q + 1) * share, end);
                 if (qb >= end) break;
-                const uint32_t sb = __builtin_bit_cast(uint32_t, s), e = sb >> 23;
-                if (es_j != 0u && (e == es_j || e == es_j + 1u)) {
-                    const bool up = e != es_j;                            // the sum is one binade above the prediction: the es + 1 maps
-                    const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)(up ? mb0[q] : ma0[q]), (int)t);
-                    const uint32_t a1 = (uint32_t)__builtin_amdgcn_readlane((int)(up ? mb1[q] : ma1[q]), (int)t);
-                    const uint32_t S = (sb & 0x7FFFFFu) | 0x800000u;
-                    const uint32_t Sn = S + ((S & 1u) ? a1 : a0);
-                    if (Sn < (1u << 24)) { s = __builtin_bit_cast(float, (e << 23) | (Sn & 0x7FFFFFu)); continue; }
+                const uint32_t tb = __builtin_bit_cast(uint32_t, s), eq = tb >> 23;
+                if (es_j >= 1u && es_j <= 254u && (eq == es_j || eq == es_j + 1u)) {
+                    const bool up = eq != es_j;                           // the sum is one binade above the prediction: the es + 1 maps
+                    const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)(up ? mb0[q] : ma0[q]), (int)L);
+                    const uint32_t a1 = (uint32_t)__builtin_amdgcn_readlane((int)(up ? mb1[q] : ma1[q]), (int)L);
+                    const uint32_t Sq = (tb & 0x7FFFFFu) | 0x800000u;
+                    const uint32_t Sn = Sq + ((Sq & 1u) ? a1 : a0);
+                    if (Sn < (1u << 24)) { s = __builtin_bit_cast(float, (eq << 23) | (Sn & 0x7FFFFFu)); continue; }
                 }
                 // walk this sub-block from the true sum: from the packed copy if the segment's wavefront made one
                 ++n_rewalk;
-                if (pack_off != 0xFFFFFFFFu)                              // PackedSrc indexes by chain element: rebase to the segment
+                if (pack_off != 0xFFFFFFFFu)                              // PackedSrc indexes by chain element: rebased to the segment
                     s = exact::ordered_walk<8>(exact::PackedSrc{st.packed + pack_off - begin}, lane, qb, qe, s);   // (16 per lane: the kernel spills)
                 else
                     s = exact::ordered_walk<8>(chain_src(st, c), lane, qb, qe, s);
             }
+            t = L + 1u;
         }
     }
     if (rewalks) *rewalks = n_rewalk;
@@ -988,8 +1040,13 @@ __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
         exact::BlockMaps maps;
 #pragma unroll
         for (int q = 0; q < 4; ++q) maps.f[q] = maps.g[q] = exact::Fn{exact::kCap, exact::kCap};
-        uint32_t pack_off = 0xFFFFFFFFu;
-        if (es >= 1u && es <= 254u && !(st.ablate & 2u)) {
+        uint32_t pack_off = 0xFFFFFFFFu, es_out = (es >= 1u && es <= 254u) ? es : 0u, exact_bits = 0u;
+        if (j == 0u) {
+            // the chain's first segment starts from +0.0, exactly: nothing to predict, it is walked for real right here
+            const uint64_t end0 = min<uint64_t>((uint64_t)c.rps * c.cy, (uint64_t)c.cx * c.cy);
+            exact_bits = __builtin_bit_cast(uint32_t, exact::ordered_walk<8>(src, lane, 0, end0, 0.0f));
+            es_out = kExactSegment;
+        } else if (es >= 1u && es <= 254u && !(st.ablate & 2u)) {
             const uint64_t begin = (uint64_t)j * c.rps * c.cy, end = min<uint64_t>(begin + (uint64_t)c.rps * c.cy, (uint64_t)c.cx * c.cy);
             const uint32_t len = (uint32_t)(end - begin);
             // will the commit re-walk this segment?  (the next segment's prediction is this segment's predicted end)
@@ -1012,7 +1069,7 @@ __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
 #pragma unroll
             for (int q = 1; q < 4; ++q) if ((int)lane == q) { a0 = maps.f[q].a0; a1 = maps.f[q].a1; b0 = maps.g[q].a0; b1 = maps.g[q].a1; }
             store_agent(&res->a0[lane], a0); store_agent(&res->a1[lane], a1); store_agent(&res->b0[lane], b0); store_agent(&res->b1[lane], b1);
-            if (lane == 0) { store_agent(&res->es, (es >= 1u && es <= 254u) ? es : 0u); store_agent(&res->pack, pack_off); }
+            if (lane == 0) { store_agent(&res->es, es_out); store_agent(&res->pack, pack_off); store_agent(&res->pad, exact_bits); }
         }
         // this segment's map and packed copy (agent-scope stores of every lane) have been performed ...
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // (a wait for this wavefront's stores; no cache write-back)
@@ -1067,11 +1124,74 @@ __global__ __launch_bounds__(256) void upgma_transpose_kernel(const float *__res
     }
 }
 
+// ---- defragmentation of the working copies ------------------------------------------------------------------------------
+// The chains of a merge gather |Ck| x n elements of d, and in the caller's layout the members of a cluster are scattered over the
+// rows and columns: one useful float per cache line fetched, and at n = 16384 the two chain launches of a merge are bound by that
+// (8.5 M gathered lines in ~110 us).  Every few hundred merges the host has the working copies re-laid out so that the members of
+// every live cluster are NEIGHBOURS, in member-list order: rows and columns are permuted alike, the member lists keep their
+// instance numbers (the order of summation is the reference's, by instance number) and get their physical twins rewritten.  Which
+// elements are added, and in which order, does not change -- only where they lie.  A cluster merged after the last
+// defragmentation reads two interleaved contiguous runs instead of one.
+//   step 1 (one workgroup): first new index of every live cluster, in live-list order (a prefix sum of the member counts)
+__global__ __launch_bounds__(1024) void upgma_defrag_offsets_kernel(UpgmaState st)
+{
+    __shared__ uint32_t wsum[16], carry;
+    const uint32_t nl = *st.n_live, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0u;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < nl; i0 += 1024) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint32_t c = i < nl ? st.mcount[st.live[i]] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if ((int)lane >= o) incl += t; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry;
+        for (uint32_t w = 0; w < wave; ++w) before += wsum[w];
+        if (i < nl) st.doff[i] = before + incl - c;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + incl;
+        __syncthreads();
+    }
+}
+//   step 2 (one wavefront per live cluster): where every new index comes from, the rewritten physical lists, instance -> index
+__global__ __launch_bounds__(256) void upgma_defrag_lists_kernel(UpgmaState st)
+{
+    const uint32_t nl = *st.n_live, lane = threadIdx.x & 63;
+    for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < nl; i += (gridDim.x * blockDim.x) >> 6) {
+        const uint32_t s = st.live[i], m0 = st.mstart[s], cnt = st.mcount[s], off = st.doff[i];
+        for (uint32_t j = lane; j < cnt; j += 64) {
+            st.dsrc[off + j] = st.ppool[m0 + j];
+            st.ppool[m0 + j] = off + j;
+            st.phys[st.pool[m0 + j]] = off + j;
+        }
+    }
+}
+//   step 3, per matrix: out[i][j] = in[src[i]][src[j]].  One workgroup per row: the source row is staged in LDS (coalesced in, gathered
+//   from LDS, coalesced out) while it fits; read from memory directly beyond that (n > 32768).
+__global__ __launch_bounds__(1024) void upgma_permute_kernel(const float *__restrict__ in, float *__restrict__ out, const uint32_t *__restrict__ src,
+                                                             uint32_t n, int staged)
+{
+    extern __shared__ float rowbuf[];
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const float *row = in + (uint64_t)src[i] * n;
+        float *o = out + (uint64_t)i * n;
+        if (staged) {
+            __syncthreads();                                              // the previous row's readers are done
+            for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) rowbuf[j] = row[j];
+            __syncthreads();
+            for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) o[j] = rowbuf[src[j]];
+        } else
+            for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) o[j] = row[src[j]];
+    }
+}
+
 __global__ void upgma_init_kernel(UpgmaState st)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < st.n) {                                                       // parents = [0..n) (:88-91); every row minimum is still to be found
-        st.size[i] = 1.0f; st.id[i] = i; st.live[i] = i; st.pos[i] = i; st.pool[i] = i; st.mstart[i] = i; st.mcount[i] = 1;
+        st.size[i] = 1.0f; st.id[i] = i; st.live[i] = i; st.pos[i] = i; st.pool[i] = i; st.ppool[i] = i; st.phys[i] = i; st.mstart[i] = i; st.mcount[i] = 1;
         st.rscan[i] = 1; st.stale[i] = i; st.rb_l[i] = __builtin_inff(); st.bpos[i] = 0xFFFFFFFFu;
     }
     if (i == 0) {
@@ -1079,7 +1199,7 @@ __global__ void upgma_init_kernel(UpgmaState st)
         *st.n_big = 0;
         *st.n_stale = st.n; *st.arrive = 0; *st.r_pending = 0; *st.n_items = 0; *st.pack_used = 0; *st.last_sq = 0;
         for (int b = 0; b < 8; ++b) st.band_count[b] = 0;
-        *st.n_ops = 0;
+        *st.n_ops = 0; *st.work = 0;
         *st.pool_used = st.n;
         *st.last_sp = 0xFFFFFFFFu;
         *st.done = (st.n > 1 && 0.0f < st.threshold) ? 0u : 1u;           // distance starts at 0.0 (:103)
@@ -1121,7 +1241,7 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     st.n = n;
     char *pool = nullptr;
     const size_t bytes_S = nn * sizeof(float), bytes_f = (size_t)n * sizeof(float), bytes_u = (size_t)n * sizeof(uint32_t);
-    const size_t bytes_lists = ((size_t)n * (n + 1) / 2 + n) * sizeof(uint32_t);    // every merged list is appended once
+    const size_t bytes_lists = ((size_t)n * (n + 1) / 2 + n) * sizeof(uint32_t);    // every merged list is appended once (twice: instance numbers, physical indices)
     const size_t bytes_d = distances_on_device ? 0 : bytes_S;
     // segments of one merge: sum over chains of ceil(rows / rows-per-segment) <= 2 (sum of chain lengths) / kSegElems + chains,
     // and the chains of one merge hold 2 |Ck| (n - |Ck|) <= n^2 / 2 elements
@@ -1132,17 +1252,19 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     // one allocation, every array on a 256-byte boundary (the row scans read S rows, sizes and ids with 16-byte loads)
     size_t off = 0;
     auto carve = [&](size_t bytes) { off = (off + 255) & ~(size_t)255; const size_t at = off; off += bytes; return at; };
-    const size_t o_S = carve(bytes_S), o_R = carve(bytes_S), o_d = carve(bytes_d), o_lists = carve(bytes_lists), o_size = carve(bytes_f),
+    const size_t o_S = carve(bytes_S), o_R = carve(bytes_S), o_d = carve(bytes_d), o_lists = carve(bytes_lists), o_plists = carve(bytes_lists), o_size = carve(bytes_f),
                  o_id = carve(bytes_u), o_live = carve(bytes_u), o_mstart = carve(bytes_u), o_mcount = carve(bytes_u), o_rscan = carve(bytes_u),
                  o_pos = carve(bytes_u), o_big = carve(bytes_u), o_bpos = carve(bytes_u), o_rbl = carve(bytes_f), o_stale = carve(bytes_u),
                  o_rbest = carve((size_t)n * sizeof(Cand)), o_ops = carve((size_t)n * sizeof(apd_cluster_op)), o_seg = carve(bytes_seg),
                  o_istart = carve(bytes_items), o_sdone = carve(bytes_items), o_ichain = carve(bytes_ichain), o_band = carve(8 * bytes_ichain), o_packed = carve(bytes_packed),
-                 o_T = carve(bytes_S), o_words = carve(256);
+                 o_T = carve(bytes_S), o_phys = carve(bytes_u), o_dsrc = carve(bytes_u), o_doff = carve(bytes_u), o_words = carve(256);
     HIP_TRY(ctx, hipMalloc((void **)&pool, off));
     st.S = (float *)(pool + o_S);
     st.R = (float *)(pool + o_R);
     float *d_copy = (float *)(pool + o_d);
     st.pool = (uint32_t *)(pool + o_lists);
+    st.ppool = (uint32_t *)(pool + o_plists);
+    st.phys = (uint32_t *)(pool + o_phys); st.dsrc = (uint32_t *)(pool + o_dsrc); st.doff = (uint32_t *)(pool + o_doff);
     st.size = (float *)(pool + o_size);
     st.id = (uint32_t *)(pool + o_id);
     st.live = (uint32_t *)(pool + o_live);
@@ -1165,12 +1287,14 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     st.packed = (float *)(pool + o_packed);
     st.pack_capacity = (uint32_t)(bytes_packed / sizeof(float));
     float *d_T = (float *)(pool + o_T);
-    st.dT = d_T;
-    st.n_live = (uint32_t *)(pool + o_words); st.n_ops = st.n_live + 1; st.done = st.n_live + 2;     // host_state reads these three
-    st.pool_used = st.n_live + 3; st.last_sp = st.n_live + 4; st.last_sq = st.n_live + 5; st.n_items = st.n_live + 6;
+    const float **d_mat = (const float **)(pool + o_words + 128);          // three device words behind the counters
+    st.mat = d_mat;
+    st.n_live = (uint32_t *)(pool + o_words); st.n_ops = st.n_live + 1; st.done = st.n_live + 2; st.work = st.n_live + 3;   // host_state reads these four
+    st.pool_used = st.n_live + 12; st.last_sp = st.n_live + 4; st.last_sq = st.n_live + 5; st.n_items = st.n_live + 6;
     st.pack_used = st.n_live + 7; st.n_stale = st.n_live + 8; st.arrive = st.n_live + 9; st.r_pending = st.n_live + 10;
     st.n_big = st.n_live + 11; st.band_count = st.n_live + 16;
-    auto fail = [&](int rc) { hipFree(pool); if (st.dbg) hipFree(st.dbg); return rc; };
+    float *spare = nullptr;                                               // two more n x n buffers: the defragmented copies rotate through d_T and these
+    auto fail = [&](int rc) { hipFree(pool); if (spare) hipFree(spare); if (st.dbg) hipFree(st.dbg); return rc; };
     if (distances_on_device) st.d = distances;
     else {
         hipError_t e0 = hipMemcpyAsync(d_copy, distances, bytes_S, hipMemcpyHostToDevice, ctx->stream);
@@ -1189,7 +1313,44 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     hipLaunchKernelGGL(upgma_init_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, st);
     hipLaunchKernelGGL(upgma_transpose_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)((n + 31) / 32) * ((n + 31) / 32), 16384)), dim3(256), 0,
                        ctx->stream, st.d, d_T, n);
-    uint32_t host_state[3] = {n, 0, 0};                                   // n_live, n_ops, done
+    // the working copies start out as the caller's matrix and its transpose
+    const float *h_mat[3] = {st.d, d_T, nullptr};
+    e = hipMemcpyAsync((void *)d_mat, h_mat, sizeof(h_mat), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return fail(APD_ERR_HIP); }
+    // Defragmentation (see upgma_permute_kernel) pays when the merges since the last one gathered many elements: the host asks for one
+    // between two batches once the new clusters of `defrag_period` or more merges sum to 8 n members (a permutation moves 4 n^2 floats
+    // at streaming speed; those merges gathered >= 16 n^2 of them one cache line apiece).  Measured at n = 16384 (round 4): a matrix whose
+    // clusters grow to hundreds of members, 5.34 -> 4.00 s with anything from 128 to 512 merges between two; 64 blobs (18 members per
+    // new cluster on average), 0.86 s without against 0.88 - 0.93 s on a fixed schedule -- hence the work criterion.
+    // APD_UPGMA_DEFRAG = least number of merges between two (0: never).  Without the two spare buffers the loop simply runs without.
+    uint32_t defrag_period = n >= 2048 ? 128u : 0u;
+    if (const char *v = std::getenv("APD_UPGMA_DEFRAG")) defrag_period = (uint32_t)std::max(0, std::atoi(v));
+    const bool defrag_forced = std::getenv("APD_UPGMA_DEFRAG_ALWAYS") != nullptr;   // tests: every `defrag_period` merges, whatever the work
+    if (defrag_period && hipMalloc((void **)&spare, 2 * bytes_S) != hipSuccess) { (void)hipGetLastError(); spare = nullptr; defrag_period = 0; }
+    std::vector<float *> free_bufs;                                       // buffers not holding a working copy right now
+    if (spare) { free_bufs.push_back(spare + nn); free_bufs.push_back(spare); }
+    const bool permute_staged = (size_t)n * sizeof(float) <= 128 * 1024;
+    if (defrag_period && permute_staged &&
+        hipFuncSetAttribute((const void *)upgma_permute_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)n * sizeof(float))) != hipSuccess) {
+        (void)hipGetLastError();
+        hipFree(spare); spare = nullptr; defrag_period = 0;
+    }
+    uint32_t defrag_at = 0, defrag_work = 0, n_defrag = 0;                // n_ops and work counter at the latest defragmentation
+    auto defragment = [&]() {
+        hipLaunchKernelGGL(upgma_defrag_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, st);
+        hipLaunchKernelGGL(upgma_defrag_lists_kernel, dim3(std::min<uint32_t>((n + 3) / 4, 4096u)), dim3(256), 0, ctx->stream, st);
+        const size_t lds = permute_staged ? (size_t)n * sizeof(float) : 0;
+        for (int m = 0; m < 2; ++m) {                                     // d, then its transpose: the same permutation of rows and columns
+            float *out = free_bufs.back();
+            free_bufs.pop_back();
+            hipLaunchKernelGGL(upgma_permute_kernel, dim3(std::min<uint32_t>(n, 2048u)), dim3(1024), lds, ctx->stream, h_mat[m], out, st.dsrc, n, (int)permute_staged);
+            if (h_mat[m] != st.d) free_bufs.push_back(const_cast<float *>(h_mat[m]));   // (the caller's matrix is never written: first round, m = 0)
+            h_mat[m] = out;
+        }
+        h_mat[2] = h_mat[0];                                              // "defragmented": any non-null word
+        return hipMemcpyAsync((void *)d_mat, h_mat, sizeof(h_mat), hipMemcpyHostToDevice, ctx->stream);
+    };
+    uint32_t host_state[4] = {n, 0, 0, 0};                                // n_live, n_ops, done, work
     // The merge loop is launch-bound (three short dependent launches per merge): a batch of merges is captured once into a
     // hipGraph and replayed until the device-side `done` flag rises; kernels launched after that return immediately.
     const uint32_t batch = 64;
@@ -1244,8 +1405,16 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
             return fail(APD_ERR_HIP);
         }
         ops_before = host_state[1];
+        if (defrag_period && host_state[0] > 2 && host_state[1] - defrag_at >= defrag_period &&
+            (defrag_forced || (uint64_t)(host_state[3] - defrag_work) >= 8ull * n)) {
+            e = defragment();
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); drop_graph(); return fail(APD_ERR_HIP); }
+            defrag_at = host_state[1]; defrag_work = host_state[3]; ++n_defrag;
+        }
     }
     drop_graph();
+    if (debug || debug_timing) std::fprintf(stderr, "[apd] upgma: %u defragmentations (period %u merges)\n", n_defrag, defrag_period);
     const uint32_t cnt = host_state[1];
     if (st.dbg) {
         std::vector<unsigned long long> g((size_t)n * 16);
@@ -1293,6 +1462,7 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     *n_roots = (uint32_t)r.size();
     *n_ops = cnt;
     hipFree(pool);
+    if (spare) hipFree(spare);
     return APD_OK;
 }
 
