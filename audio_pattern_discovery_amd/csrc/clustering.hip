@@ -160,6 +160,11 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
     return k;
 }
 
+// What the chain and segment launches need to know about the merge they serve, written by the select launch's bookkeeping as ONE
+// 32-byte record: a single load instead of a chain of dependent ones (last_sp -> mstart / mcount -> ...).  sp == 0xFFFFFFFF: no merge
+// is waiting for its chains (the loop has ended, or the degenerate (0, 0) merge was emitted).
+struct MergeRec { uint32_t sp, sq, K, ms, nl, nb, t, pad; };   // new cluster's slot, dead slot, |Ck|, offset of Ck's lists, live slots, big clusters, n_ops
+
 struct UpgmaState {
     const float *d;           // [n][n] raw distances as the caller laid them out (read only): threshold and the initial S
     const float *const *mat;  // device words: [0] the WORKING copy of d, [1] of its transpose -- rows and columns in `phys` order (the caller's
@@ -188,6 +193,7 @@ struct UpgmaState {
     uint32_t *arrive;         // workgroups of the running select launch that have finished their rows
     uint32_t *r_pending;      // 1: R[.][last_sp] += R[.][last_sq] of the latest merge has not been applied yet
     uint32_t *last_sq;        // slot that died in the latest merge
+    uint32_t *rec;            // MergeRec of the latest merge (32-byte aligned)
     apd_cluster_op *ops;      // [n]
     uint32_t *n_ops;
     uint32_t *work;           // sum of the new clusters' member counts so far (wraps; the host looks at differences): when to defragment
@@ -222,12 +228,12 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
     __shared__ uint32_t is_last, kwin, lmin_key;
     __shared__ float kwin_l;
     __shared__ unsigned long long kmin;
-    if (*st.done != 0) return;
     const uint32_t n = st.n;
     const unsigned long long t_entry = st.dbg ? wall_clock64() : 0ull;
     // every scalar this workgroup needs, loaded together (one memory round trip, not one per dependent step)
-    const uint32_t pending = *st.r_pending, sp0 = *st.last_sp, sq0 = *st.last_sq, ns = *st.n_stale;
+    const uint32_t finished = *st.done, pending = *st.r_pending, sp0 = *st.last_sp, sq0 = *st.last_sq, ns = *st.n_stale;
     const uint32_t first_stale = st.stale[min(blockIdx.x, n - 1)];       // meaningful if blockIdx.x < ns
+    if (finished != 0u) return;
     if (pending != 0u) {
         // the R update is dealt from the far end of the grid: the stale rows start at workgroup 0
         for (uint32_t x = (gridDim.x - 1u - blockIdx.x) * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
     if (threadIdx.x < 8) st.band_count[threadIdx.x] = 0u;
     // global arg-min, two passes over the linkages alone (coalesced, independent loads): the smallest value, then `better` among
     // the rows that hold it (its tie rule needs their ids; almost always a single row)
-    if (threadIdx.x == 0) { lmin_key = 0xFFFFFFFFu; kmin = ~0ull; kwin = 0xFFFFFFFFu; }
+    if (threadIdx.x == 0) { lmin_key = 0xFFFFFFFFu; kmin = ~0ull; win = Cand{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0}; }
     __syncthreads();
     float lmin = __builtin_inff();
     constexpr uint32_t kAhead = 8;                                        // loads in flight per thread
@@ -335,11 +341,12 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
         const uint32_t kk = lmin_key;
         lmin = kk == 0xFFFFFFFFu ? __builtin_inff() : __builtin_bit_cast(float, (kk & 0x80000000u) ? (kk & 0x7FFFFFFFu) : ~kk);
     }
-    // ... then, among the rows that hold it, the lowest (idp, idq) -- tracked as scalars plus the row, the winner's record read
-    // back once.  (Carrying a whole Cand through `if (better(cc, best)) best = cc` here was compiled into a partial assignment:
-    // (l, idp, idq) of one row with (sp, sq) of another when a thread met two tied rows -- caught by the tie-laden matrices of
-    // tests/test_gpu_clustering.py.)
-    uint32_t bidp = 0xFFFFFFFFu, bidq = 0xFFFFFFFFu, brow = 0xFFFFFFFFu;
+    // ... then, among the rows that hold it, the lowest (idp, idq) -- tracked as scalars, and published by the thread that holds the
+    // winner (no read-back of its record: one dependent round trip less).  (Carrying a whole Cand through
+    // `if (better(cc, best)) best = cc` here was compiled into a partial assignment: (l, idp, idq) of one row with (sp, sq) of another
+    // when a thread met two tied rows -- caught by the tie-laden matrices of tests/test_gpu_clustering.py.)
+    uint32_t bidp = 0xFFFFFFFFu, bidq = 0xFFFFFFFFu, brow = 0xFFFFFFFFu, bsq2 = 0u;
+    float bl2 = __builtin_inff();
     if (lmin < __builtin_inff())
         for (uint32_t c0 = threadIdx.x; c0 < n; c0 += kAhead * blockDim.x) {
             float v[kAhead];
@@ -349,9 +356,11 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
             for (uint32_t u = 0; u < kAhead; ++u) {
                 const uint32_t c = c0 + u * blockDim.x;
                 if (c < n && v[u] == lmin) {
-                    const uint32_t ip = st.rbest[c].idp, iq = st.rbest[c].idq;
+                    const Cand *o = st.rbest + c;
+                    const uint32_t ip = o->idp, iq = o->idq, osq = o->sq;
+                    const float ol = o->l;                                // (lmin up to the sign of a zero: the record's own bits are reported)
                     const bool take = ip < bidp || (ip == bidp && iq < bidq);
-                    bidp = take ? ip : bidp; bidq = take ? iq : bidq; brow = take ? c : brow;
+                    bidp = take ? ip : bidp; bidq = take ? iq : bidq; brow = take ? c : brow; bsq2 = take ? osq : bsq2; bl2 = take ? ol : bl2;
                 }
             }
         }
@@ -360,9 +369,7 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
         const unsigned long long wkey = wave_min_u64(key);
         if ((threadIdx.x & 63) == 0 && wkey != ~0ull) atomicMin(&kmin, wkey);
         __syncthreads();
-        if (key != ~0ull && key == kmin) kwin = brow;
-        __syncthreads();
-        if (threadIdx.x == 0) win = kwin != 0xFFFFFFFFu ? st.rbest[kwin] : Cand{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0};
+        if (key != ~0ull && key == kmin) win = Cand{bl2, bidp, bidq, brow, bsq2};
         __syncthreads();
     }
     const unsigned long long t_argmin = st.dbg ? wall_clock64() : 0ull;
@@ -376,6 +383,7 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
             st.ops[t] = apd_cluster_op{0u, 0u, k, __builtin_inff(), (uint32_t)APD_SEQUENCE2SEQUENCE};
             *st.n_ops = t + 1;
             *st.last_sp = 0xFFFFFFFFu;
+            st.rec[0] = 0xFFFFFFFFu;                                      // no chains to sum
             *st.done = 2;                                                 // INF < threshold is false: loop ends (:104)
         }
         return;
@@ -398,6 +406,7 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
             out[(from_p ? i : i - cp) + lo] = v; pout[(from_p ? i : i - cp) + lo] = pv;
         }
     }
+    __syncthreads();                                                      // every wavefront has read what thread 0 is about to overwrite
     if (threadIdx.x == 0) {
         if (st.dbg) {
             unsigned long long *g = st.dbg + (uint64_t)t * 16;
@@ -431,7 +440,12 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
         st.rscan[w.sp] = 1;                                               // the new cluster's row is new
         st.stale[0] = w.sp;
         *st.n_stale = 1u;
-        if (nl - 1 <= 1 || !(w.l < st.threshold)) *st.done = 1;           // while n_clusters > 1 && distance < threshold (:104)
+        const bool ends = nl - 1 <= 1 || !(w.l < st.threshold);           // while n_clusters > 1 && distance < threshold (:104)
+        if (ends) *st.done = 1;
+        // the record the chain / segment launches read (two 16-byte stores); a merge that ends the loop leaves no chains to sum
+        const uint32_t nb_now = *st.n_big;
+        reinterpret_cast<uint4 *>(st.rec)[1] = uint4{nl - 1, nb_now, t + 1, 0u};
+        reinterpret_cast<uint4 *>(st.rec)[0] = uint4{ends ? 0xFFFFFFFFu : w.sp, w.sq, cp + cq, used};
     }
 }
 
@@ -513,6 +527,9 @@ __device__ __forceinline__ float readlane_f(float v, int lane)
 // Where a chain's elements come from: gathered from the distance matrix (element e = a * cy + b is d[lx[a] * n + ly[b]]),
 // or from the packed copy a segment wavefront left behind (contiguous, so that re-walking a segment costs 1/16 of the
 // cache lines of the gather).
+// The working copies are reached through pointers that were themselves loaded from memory (st.mat[]): to the compiler they could point
+// anywhere (FLAT loads, which count on both wait counters and so cannot be waited for one by one).  Global address space, said aloud:
+typedef const float __attribute__((address_space(1))) *GlobalF;
 struct GatherSrc {
     const float *m; uint64_t sx, sy;                                    // element (a, b) is m[lx[a] * sx + ly[b] * sy]
     const uint32_t *lx; uint32_t cx; const uint32_t *ly; uint32_t cy;
@@ -538,7 +555,7 @@ struct GatherSrc {
         for (int j = 0; j < K; ++j) { ra[j] = lx[aa[j]]; cb[j] = ly[bb[j]]; }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const float v = m[(uint64_t)ra[j] * sx + (uint64_t)cb[j] * sy];
+            const float v = ((GlobalF)m)[(uint64_t)ra[j] * sx + (uint64_t)cb[j] * sy];
             x[j] = first + j < total ? v : 0.0f;                        // padding: +0.0 is the identity
         }
     }
@@ -547,7 +564,7 @@ struct GatherSrc {
         uint32_t a, b;
         if (total <= 0xFFFFFFFFull) { a = (uint32_t)e / cy; b = (uint32_t)e - a * cy; }
         else { a = (uint32_t)(e / cy); b = (uint32_t)(e - (uint64_t)a * cy); }
-        return m[(uint64_t)lx[a] * sx + (uint64_t)ly[b] * sy];
+        return ((GlobalF)m)[(uint64_t)lx[a] * sx + (uint64_t)ly[b] * sy];
     }
 };
 struct PackedSrc {
@@ -740,17 +757,23 @@ struct Chain {
 };
 
 // Chain id w = 2 * (slot of the other cluster) + direction: no trip through the live list to find out what a chain is.
-__device__ __forceinline__ Chain get_chain(const UpgmaState &st, uint32_t w, uint32_t sp)
+__device__ __forceinline__ MergeRec load_rec(const UpgmaState &st)
+{
+    const uint4 a = reinterpret_cast<const uint4 *>(st.rec)[0], b = reinterpret_cast<const uint4 *>(st.rec)[1];
+    return MergeRec{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+}
+
+__device__ __forceinline__ Chain get_chain(const UpgmaState &st, uint32_t w, const MergeRec &m)
 {
     Chain c{};
     c.dir = w & 1u;
     c.s = w >> 1;
-    if (c.s == sp) return c;                                             // nseg = 0
-    const uint32_t sx = c.dir ? c.s : sp, sy = c.dir ? sp : c.s;
-    const uint32_t mx = st.mstart[sx], my = st.mstart[sy];
+    if (c.s == m.sp) return c;                                           // nseg = 0
+    const uint32_t ms_s = st.mstart[c.s], cnt_s = st.mcount[c.s];        // the new cluster's own list comes with the record
+    const uint32_t mx = c.dir ? ms_s : m.ms, my = c.dir ? m.ms : ms_s;
     c.lx = st.pool + mx; c.ly = st.pool + my; c.plx = st.ppool + mx; c.ply = st.ppool + my;
-    c.cx = st.mcount[sx]; c.cy = st.mcount[sy];
-    c.slot_y = sy;
+    c.cx = c.dir ? cnt_s : m.K; c.cy = c.dir ? m.K : cnt_s;
+    c.slot_y = c.dir ? m.sp : c.s;
     const uint64_t len = (uint64_t)c.cx * c.cy;
     if (len <= kLaneChain && (c.dir ? c.cx : c.cy) == 1u) { c.rps = c.cx; c.nseg = 1; c.lane_chain = true; return c; }
     if (len <= st.short_chain) { c.rps = c.cx; c.nseg = 1; return c; }
@@ -770,30 +793,37 @@ __device__ __forceinline__ exact::GatherSrc chain_src(const UpgmaState &st, cons
     return exact::GatherSrc{dT, 1, st.n, c.plx, c.cx, c.ply, c.cy};
 }
 
-// what lane 0 does with a finished sum (the tail of the former one-kernel update)
-__device__ __forceinline__ void finish_chain(const UpgmaState &st, const Chain &c, uint32_t sp, float acc)
+// what lane 0 does with a finished sum (the tail of the former one-kernel update).  Its operands -- the row's cached best pair, the
+// sizes and ids of the candidate -- do not depend on the sum: load_finish() requests them BEFORE the sum's own loads, so the end of a
+// chain is stores only instead of two more dependent round trips on the launch's critical path.
+struct FinishOps { Cand old; float sz_s, sz_sp; uint32_t id_s, id_sp; };
+__device__ __forceinline__ FinishOps load_finish(const UpgmaState &st, uint32_t s, uint32_t dir, uint32_t sp)
 {
-    if (c.dir) {
-        st.S[(uint64_t)c.s * st.n + sp] = acc;
+    FinishOps f{};
+    if (dir) { f.old = st.rbest[s]; f.sz_s = st.size[s]; f.sz_sp = st.size[sp]; f.id_s = st.id[s]; f.id_sp = st.id[sp]; }
+    return f;
+}
+__device__ __forceinline__ void finish_chain(const UpgmaState &st, uint32_t s, uint32_t dir, const MergeRec &m, float acc, const FinishOps &f)
+{
+    if (dir) {
+        st.S[(uint64_t)s * st.n + m.sp] = acc;
         // row s: its cached best pair survives unless it pointed at one of the two merged slots; the new entry may beat it
-        const Cand old = st.rbest[c.s];
-        if (old.sq == sp || old.sq == *st.last_sq) {
-            if (atomicExch(&st.rscan[c.s], 1u) == 0u) st.stale[atomicAdd(st.n_stale, 1u)] = c.s;   // re-scanned by the next select launch
+        if (f.old.sq == m.sp || f.old.sq == m.sq) {
+            if (atomicExch(&st.rscan[s], 1u) == 0u) st.stale[atomicAdd(st.n_stale, 1u)] = s;   // re-scanned by the next select launch
         } else {
-            const Cand cnd{acc / (st.size[c.s] * st.size[sp]), st.id[c.s], st.id[sp], c.s, sp};
-            if (better(cnd, old)) { st.rbest[c.s] = cnd; st.rb_l[c.s] = cnd.l; }
+            const Cand cnd{acc / (f.sz_s * f.sz_sp), f.id_s, f.id_sp, s, m.sp};
+            if (better(cnd, f.old)) { st.rbest[s] = cnd; st.rb_l[s] = cnd.l; }
         }
-    } else st.S[(uint64_t)sp * st.n + c.s] = acc;
+    } else st.S[(uint64_t)m.sp * st.n + s] = acc;
 }
 
 }  // namespace
 
 // The predicted running sum at every segment start of a segmented chain, from the row sums in R (one wavefront).  R's update
 // for the latest merge is applied by the NEXT select launch, so the new cluster's column is read as the sum of its two halves.
-__device__ void predict_chain(const UpgmaState &st, const Chain &c, uint32_t sp, uint32_t lane, SegRes *res)
+__device__ void predict_chain(const UpgmaState &st, const Chain &c, uint32_t sp, uint32_t sq, uint32_t lane, SegRes *res)
 {
     const bool fresh = c.slot_y == sp;
-    const uint32_t sq = *st.last_sq;
     float base = 0.0f;
     for (uint32_t a0 = 0; a0 < c.cx; a0 += 64) {
         const uint32_t a = a0 + lane;
@@ -826,78 +856,81 @@ __device__ void predict_chain(const UpgmaState &st, const Chain &c, uint32_t sp,
 //    which chain they belong to, and writes the predicted sums the segment launch needs.
 __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
 {
-    const uint32_t sp = *st.last_sp;
-    if (sp == 0xFFFFFFFFu || *st.done != 0) return;
     const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    const uint32_t nl = *st.n_live;
     const uint32_t group_waves = 2u * ((st.n + 63u) / 64u);
+    // First round trip: the merge record, and with it the one list entry whose ADDRESS does not depend on the record (a singleton
+    // group's live slot, a chain wavefront's big cluster) -- requested together.
+    const bool grp = wid < group_waves;
+    const uint32_t v = grp ? 0u : wid - group_waves, cidx = (wid >> 1) * 64u + lane;
+    const uint32_t spec = grp ? st.live[min(cidx, st.n - 1u)] : st.big[min(v >> 1, st.n - 1u)];
+    const MergeRec m = load_rec(st);
+    const uint32_t sp = m.sp;
+    if (sp == 0xFFFFFFFFu) return;
     auto stamp = [&]() __attribute__((always_inline)) {                  // tuning aid: when the last wavefront with work finished
-        if (st.dbg && lane == 0) atomicMax(st.dbg + (uint64_t)(*st.n_ops - 1u) * 16 + 7, (unsigned long long)wall_clock64());
+        if (st.dbg && lane == 0) atomicMax(st.dbg + (uint64_t)(m.t - 1u) * 16 + 7, (unsigned long long)wall_clock64());
     };
-    if (wid < group_waves) {
-        const uint32_t dir = wid & 1u, cidx = (wid >> 1) * 64u + lane;
-        if ((wid >> 1) * 64u >= nl) return;
+    if (grp) {
+        const uint32_t dir = wid & 1u, K = m.K;
+        if ((wid >> 1) * 64u >= m.nl) return;
         // A singleton's slot holds the instance of the same number (slots are instance ids until they merge), so its chain needs no
-        // member-list lookups: live[cidx] -> mcount -> the loads.  (finish_chain only wants the slot and the direction.)
-        const uint32_t K = st.mcount[sp], ms = st.mstart[sp];
-        const uint32_t own = cidx < nl ? st.live[cidx] : sp;
-        const bool active = own != sp && K <= kLaneChain && st.mcount[own] == 1u;
+        // member-list lookups.  Second round trip: is it a singleton, its physical column, what the end of the chain needs (the
+        // row's cached best pair, the sizes and ids of its candidate) and the new cluster's member list; third: the elements.
+        const uint32_t own = cidx < m.nl ? spec : sp;
+        const uint32_t cnt_own = st.mcount[own];
+        const uint64_t col = st.phys[own];
+        const FinishOps fo = load_finish(st, own, dir, sp);
+        const bool active = own != sp && K <= kLaneChain && cnt_own == 1u;
         if (__ballot(active) == 0ull) return;
         // element i is M[ck[i] * n + phys[own]]
-        const uint32_t *ck = st.ppool + ms;                             // wave-uniform (physical rows)
-        const float *M = st.mat[dir];                                   // dir 1: the transposed copy
+        const uint32_t *ck = st.ppool + m.ms;                           // wave-uniform (physical rows)
+        const exact::GlobalF M = (exact::GlobalF)st.mat[dir];          // dir 1: the transposed copy
         const uint64_t rs = st.n;
-        const uint64_t col = active ? (uint64_t)st.phys[own] : 0;
-        // what the end of the chain needs (the row's cached best pair, the sizes and ids of its candidate), requested before the
-        // sum's own loads instead of after them: one memory round trip less on the launch's critical path
-        Cand old{};
-        float sz_own = 0.0f, sz_sp = 0.0f;
-        uint32_t id_own = 0, id_sp = 0, lsq = 0;
-        if (dir == 1u && active) { old = st.rbest[own]; sz_own = st.size[own]; sz_sp = st.size[sp]; id_own = st.id[own]; id_sp = st.id[sp]; lsq = *st.last_sq; }
         float s = 0.0f;                                                  // distance = 0.0 (clustering.rs:154)
-        constexpr int kAhead = 32;
-        for (uint32_t i0 = 0; i0 < K; i0 += kAhead) {
-            float x[kAhead];
+        if (K <= 4u) {                                                   // most merges: no point in issuing 32 loads for two members
+            float x[4];
 #pragma unroll
-            for (int u = 0; u < kAhead; ++u) {
-                const uint32_t r = ck[min(i0 + u, K - 1)];              // uniform address: a scalar load
-                x[u] = M[(uint64_t)r * rs + col];
-            }
+            for (int u = 0; u < 4; ++u) x[u] = M[(uint64_t)ck[min((uint32_t)u, K - 1)] * rs + col];
 #pragma unroll
-            for (int u = 0; u < kAhead; ++u) if (i0 + u < K) s = s + x[u];   // distance += d[x][y] (:162), in order
-        }
-        if (active) {                                                    // finish_chain with the operands loaded above
-            if (dir == 1u) {
-                st.S[(uint64_t)own * st.n + sp] = s;
-                if (old.sq == sp || old.sq == lsq) {
-                    if (atomicExch(&st.rscan[own], 1u) == 0u) st.stale[atomicAdd(st.n_stale, 1u)] = own;
-                } else {
-                    const Cand cnd{s / (sz_own * sz_sp), id_own, id_sp, own, sp};
-                    if (better(cnd, old)) { st.rbest[own] = cnd; st.rb_l[own] = cnd.l; }
+            for (int u = 0; u < 4; ++u) if ((uint32_t)u < K) s = s + x[u];
+        } else {
+            constexpr int kAhead = 32;
+            for (uint32_t i0 = 0; i0 < K; i0 += kAhead) {
+                float x[kAhead];
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) {
+                    const uint32_t r = ck[min(i0 + u, K - 1)];          // uniform address: a scalar load
+                    x[u] = M[(uint64_t)r * rs + col];
                 }
-            } else st.S[(uint64_t)sp * st.n + own] = s;
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) if (i0 + u < K) s = s + x[u];   // distance += d[x][y] (:162), in order
+            }
         }
+        if (active) finish_chain(st, own, dir, m, s, fo);
         stamp();
         return;
     }
-    // wavefronts [0, 2 n_big): the chains against the clusters of two or more members; behind them, only when the NEW cluster is too
-    // large for one lane per singleton (more than kLaneChain members), one wavefront per chain against a singleton
-    const uint32_t v = wid - group_waves, nb2 = 2u * *st.n_big;
+    // chains [0, 2 n_big): against the clusters of two or more members; behind them, only when the NEW cluster is too large for one
+    // lane per singleton (more than kLaneChain members), one chain per singleton and direction.  The grid holds one chain wavefront per
+    // possible chain (2 n), so the loop below runs once; it is a loop so that a smaller grid stays correct (measured: no gain).
+    const uint32_t nb2 = 2u * m.nb, n_chains = nb2 + (m.K > kLaneChain ? 2u * m.nl : 0u);
+    const uint32_t chain_waves = ((gridDim.x * blockDim.x) >> 6) - group_waves;
+    for (uint32_t vv = v; vv < n_chains; vv += chain_waves) {
     uint32_t w;
-    if (v < nb2) w = 2u * st.big[v >> 1] + (v & 1u);
+    if (vv < nb2) w = 2u * (vv == v ? spec : st.big[vv >> 1]) + (vv & 1u);
     else {
-        if (st.mcount[sp] <= kLaneChain || v - nb2 >= 2u * nl) return;
-        const uint32_t s1 = st.live[(v - nb2) >> 1];
-        if (st.mcount[s1] != 1u) return;                                 // covered by the first range
-        w = 2u * s1 + ((v - nb2) & 1u);
+        const uint32_t s1 = st.live[(vv - nb2) >> 1];
+        if (st.mcount[s1] != 1u) continue;                               // covered by the first range
+        w = 2u * s1 + ((vv - nb2) & 1u);
     }
-    const Chain c = get_chain(st, w, sp);
-    if (c.nseg == 0 || c.lane_chain) return;
+    if ((w >> 1) == sp) continue;
+    const FinishOps fo = load_finish(st, w >> 1, w & 1u, sp);            // second round trip, together with get_chain's two loads
+    const Chain c = get_chain(st, w, m);
+    if (c.nseg == 0 || c.lane_chain) continue;
     if (c.nseg == 1) {
         const float acc = exact::ordered_walk<8>(chain_src(st, c), lane, 0, (uint64_t)c.cx * c.cy, 0.0f);
-        if (lane == 0) finish_chain(st, c, sp, acc);
+        if (lane == 0) finish_chain(st, c.s, c.dir, m, acc, fo);
         stamp();
-        return;
+        continue;
     }
     uint32_t base = 0;
     if (lane == 0) { base = atomicAdd(st.n_items, c.nseg); st.item_start[w] = base; st.seg_done[w] = 0u; }
@@ -907,7 +940,7 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
     // |Ck|; a dir-1 chain reads those rows of the transposed copy at the columns of its own members -- band = (first column) * 8 / n.
     // A locality hint only, any assignment is correct -- and a measured non-effect (round 4, same box, APD_UPGMA_ABLATE=16 deals the
     // items round robin instead: chain proxy 5.68 vs 5.61 s, 16384-blob 0.892 vs 0.908 s): the gathers are not what launch 3 waits for.
-    if (st.ablate & 8u) return;
+    if (st.ablate & 8u) continue;
     for (uint32_t j = lane; j < c.nseg; j += 64) {
         st.item_chain[base + j] = w;
         const uint32_t a0 = j * c.rps;
@@ -915,8 +948,9 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
         if (st.ablate & 16u) band = (base + j) & 7u;                     // A/B: round robin (results stay right)
         st.band_items[(uint64_t)min(band, 7u) * st.band_cap + atomicAdd(&st.band_count[min(band, 7u)], 1u)] = base + j;
     }
-    predict_chain(st, c, sp, lane, st.seg + base);
+    predict_chain(st, c, sp, m.sq, lane, st.seg + base);
     stamp();
+    }
 }
 
 // Launch 3 of a merge: the segments of the long chains.  A segment gets its integer map under the predicted exponent
@@ -933,8 +967,9 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
 // The FIRST segment starts from +0.0 exactly, so its wavefront has already walked it for real: kExactSegment, the sum in `pad`.
 constexpr uint32_t kExactSegment = 0xFFFFFFFFu;
 
-__device__ void commit_chain(const UpgmaState &st, const Chain &c, uint32_t sp, uint32_t lane, const SegRes *res, uint32_t *rewalks = nullptr)
+__device__ void commit_chain(const UpgmaState &st, const Chain &c, const MergeRec &m, uint32_t lane, const SegRes *res, uint32_t *rewalks = nullptr)
 {
+    const FinishOps fo = load_finish(st, c.s, c.dir, m.sp);              // requested with the first batch of segment results
     uint32_t n_rewalk = 0;
     const uint64_t total = (uint64_t)c.cx * c.cy, seg_len = (uint64_t)c.rps * c.cy;
     float s = 0.0f;
@@ -1014,25 +1049,25 @@ __device__ void commit_chain(const UpgmaState &st, const Chain &c, uint32_t sp, 
         }
     }
     if (rewalks) *rewalks = n_rewalk;
-    if (lane == 0) finish_chain(st, c, sp, s);
+    if (lane == 0) finish_chain(st, c.s, c.dir, m, s, fo);
 }
 
 __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
 {
-    const uint32_t sp = *st.last_sp;
-    if (sp == 0xFFFFFFFFu || *st.done != 0) return;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t n_items = *st.n_items;
-    if (n_items == 0u) return;
     const uint32_t xcd = blockIdx.x & 7u, v = (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6);   // v-th wavefront of this XCD (blocks b and b + 8 share one)
     const uint32_t waves_per_xcd = (gridDim.x >> 3) * 4u;                                      // gridDim.x is a multiple of 64
-    const uint32_t mine = st.band_count[xcd];
+    // one round trip: the item count (zero for most merges: this launch is then over), the XCD's share, the merge record
+    const uint32_t n_items = *st.n_items, mine = st.band_count[xcd];
+    const MergeRec m = load_rec(st);
+    const uint32_t sp = m.sp;
+    if (sp == 0xFFFFFFFFu || n_items == 0u) return;
     const uint32_t *list = st.band_items + (uint64_t)xcd * st.band_cap;
     for (uint32_t k = v; k < mine; k += waves_per_xcd) {
         const uint32_t item = list[k];
         if (st.ablate & 4u) continue;
         const uint32_t w = st.item_chain[item];
-        const Chain c = get_chain(st, w, sp);
+        const Chain c = get_chain(st, w, m);
         const exact::GatherSrc src = chain_src(st, c);
         const uint32_t first = st.item_start[w], j = item - first;
         SegRes *res = st.seg + item;
@@ -1062,7 +1097,7 @@ __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
             }
             maps = exact::segment_fn(src, lane, begin, end, es, pack_off != 0xFFFFFFFFu ? st.packed + pack_off : nullptr);
         }
-        if (st.dbg && lane == 0 && k == 0 && xcd == 0) st.dbg[(uint64_t)(*st.n_ops - 1u) * 16 + 10] = n_items;
+        if (st.dbg && lane == 0 && k == 0 && xcd == 0) st.dbg[(uint64_t)(m.t - 1u) * 16 + 10] = n_items;
         uint32_t finished = 0;
         if (lane < 4) {                                                  // lane q publishes sub-block q's maps (uniform values: any lane holds them)
             uint32_t a0 = maps.f[0].a0, a1 = maps.f[0].a1, b0 = maps.g[0].a0, b1 = maps.g[0].a1;
@@ -1079,9 +1114,9 @@ __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             const unsigned long long t0 = st.dbg ? wall_clock64() : 0ull;
             uint32_t rw = 0;
-            commit_chain(st, c, sp, lane, st.seg + first, &rw);          // reads the other wavefronts' results with agent-scope loads
+            commit_chain(st, c, m, lane, st.seg + first, &rw);          // reads the other wavefronts' results with agent-scope loads
             if (st.dbg && lane == 0) {                                   // tuning aid, stamped by the committing wavefronts only (a few dozen per merge)
-                unsigned long long *g = st.dbg + (uint64_t)(*st.n_ops - 1u) * 16;
+                unsigned long long *g = st.dbg + (uint64_t)(m.t - 1u) * 16;
                 const unsigned long long t1 = wall_clock64();
                 atomicMax(g + 8, t1);                                    // end of the merge's last commit
                 atomicMax(g + 9, t1 - t0);                               // the longest commit
@@ -1202,6 +1237,7 @@ __global__ void upgma_init_kernel(UpgmaState st)
         *st.n_ops = 0; *st.work = 0;
         *st.pool_used = st.n;
         *st.last_sp = 0xFFFFFFFFu;
+        st.rec[0] = 0xFFFFFFFFu;
         *st.done = (st.n > 1 && 0.0f < st.threshold) ? 0u : 1u;           // distance starts at 0.0 (:103)
     }
 }
@@ -1292,7 +1328,7 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     st.n_live = (uint32_t *)(pool + o_words); st.n_ops = st.n_live + 1; st.done = st.n_live + 2; st.work = st.n_live + 3;   // host_state reads these four
     st.pool_used = st.n_live + 12; st.last_sp = st.n_live + 4; st.last_sq = st.n_live + 5; st.n_items = st.n_live + 6;
     st.pack_used = st.n_live + 7; st.n_stale = st.n_live + 8; st.arrive = st.n_live + 9; st.r_pending = st.n_live + 10;
-    st.n_big = st.n_live + 11; st.band_count = st.n_live + 16;
+    st.n_big = st.n_live + 11; st.band_count = st.n_live + 16; st.rec = st.n_live + 24;   // (words 24..31: 32-byte aligned)
     float *spare = nullptr;                                               // two more n x n buffers: the defragmented copies rotate through d_T and these
     auto fail = [&](int rc) { hipFree(pool); if (spare) hipFree(spare); if (st.dbg) hipFree(st.dbg); return rc; };
     if (distances_on_device) st.d = distances;
@@ -1356,10 +1392,15 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     const uint32_t batch = 64;
     // stale rows per merge: a handful (the first launch loops over all n); every workgroup costs an arrival, 8 .. 64 measured alike
     const uint32_t select_blocks = std::min<uint32_t>(std::max<uint32_t>(n / 128u, 1u), 64u);
+    // Grid sizes (round 4, same-box A/B): one resident round of workgroups that take chains / items in turn (768 chain, 512 segment
+    // workgroups) instead of one wavefront per possible chain / item changes nothing at n = 4096 (0.116 vs 0.115 s: a launch that finds
+    // nothing to do costs its ~4 us boundary whatever its grid) and LOSES at n = 16384 (blobs 0.83 -> 0.93 s, chain proxy 2.79 -> 3.10 s):
+    // a wavefront that walks several chains or segments one after the other is what the critical path of a large merge is made of.
     const uint32_t chain_waves = 2 * ((n + 63) / 64) + 2 * n;             // singleton groups, then one wavefront per (other cluster, direction)
     const uint32_t chain_blocks = (chain_waves + 3) / 4;
     // one wavefront per item up to 32768 items (a wavefront that commits a chain must not hold other items back), grid-stride beyond
-    const uint32_t segment_blocks = (std::min((2 * n + 3) / 4, 8192u) + 63u) / 64u * 64u;   // groups of 32 wavefronts per XCD
+    uint32_t segment_blocks = (std::min((2 * n + 3) / 4, 8192u) + 63u) / 64u * 64u;   // groups of 32 wavefronts per XCD
+    if (const char *v = std::getenv("APD_UPGMA_SEGMENT_BLOCKS")) segment_blocks = (uint32_t)std::max(64, std::atoi(v)) / 64u * 64u;   // tuning
     const bool debug_timing = std::getenv("APD_DEBUG_UPGMA_TIMING") != nullptr;   // tuning aid: phase stamps of every select launch
     if (debug_timing && hipMalloc((void **)&st.dbg, (size_t)n * 16 * sizeof(unsigned long long)) == hipSuccess)
         (void)hipMemsetAsync(st.dbg, 0, (size_t)n * 16 * sizeof(unsigned long long), ctx->stream);
@@ -1420,8 +1461,10 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
         std::vector<unsigned long long> g((size_t)n * 16);
         if (hipMemcpy(g.data(), st.dbg, g.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess && cnt > 1) {
             double ph[4] = {0, 0, 0, 0}, stale = 0, merged = 0, chain = 0, seg = 0, gap = 0, maps = 0, items = 0, longest = 0, rewalk = 0, cstart = 0, csum = 0, ccnt = 0, rwsum = 0;
+            double stamped = 0;
             for (uint32_t t = 1; t + 1 < cnt; ++t) {                      // stamps: 100 MHz; merge 0 scans every row, the last merge ends the loop
                 const unsigned long long *q = &g[(size_t)t * 16];
+                stamped += 1;
                 for (int k = 0; k < 4; ++k) ph[k] += (double)(q[k + 1] - q[k]) * 0.01;
                 stale += (double)q[5]; merged += (double)q[6];
                 chain += (double)(q[7] - q[4]) * 0.01;                    // end of select's bookkeeping -> last wavefront of the chain launch
@@ -1431,7 +1474,7 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
                 if (q[12] > q[7]) cstart += (double)(q[12] - q[7]) * 0.01;
                 csum += (double)q[13] * 0.01; ccnt += (double)q[14]; rwsum += (double)q[15];
             }
-            const double m = std::max(1.0, (double)cnt - 2.0);
+            const double m = std::max(1.0, stamped);
             std::fprintf(stderr, "[apd] upgma us per merge: select [rows %.2f | arrive %.2f | argmin %.2f | lists %.2f] chain launch %.2f, segment launch %.2f, "
                                  "(longest commit %.2f; %.1f segments per merge, longest chain %.1f, %.1f of its sub-blocks walked) to the next select's entry %.2f ; stale rows %.1f, merged list %.1f members\n",
                          ph[0] / m, ph[1] / m, ph[2] / m, ph[3] / m, chain / m, seg / m, maps / m, items / m, longest / m, rewalk / m, gap / m, stale / m, merged / m);

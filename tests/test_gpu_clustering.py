@@ -232,3 +232,4 @@ def test_exact_sums_survive_extreme_value_ranges(ctx, oracle, kind):
     assert np.array_equal(gd[~both_nan].view(np.uint32), wd[~both_nan].view(np.uint32)), "linkage bits differ"
     assert sorted(roots) == want_roots
     assert len(ops) > 100
+
