@@ -194,6 +194,9 @@ struct UpgmaState {
     uint32_t *r_pending;      // 1: R[.][last_sp] += R[.][last_sq] of the latest merge has not been applied yet
     uint32_t *last_sq;        // slot that died in the latest merge
     uint32_t *rec;            // MergeRec of the latest merge (32-byte aligned)
+    uint32_t *items_total;    // segments made so far (wraps; the host looks at differences): does the segment launch have anything to do?
+    uint32_t *whole_walks;    // long chains walked whole by the chain launch of a two-launch batch (see no_seg)
+    uint32_t no_seg;          // 1: this launch belongs to a batch WITHOUT segment launches
     apd_cluster_op *ops;      // [n]
     uint32_t *n_ops;
     uint32_t *work;           // sum of the new clusters' member counts so far (wraps; the host looks at differences): when to defragment
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
     __syncthreads();
     if (is_last == 0u) return;
     const unsigned long long t_last = st.dbg ? wall_clock64() : 0ull;
-    if (threadIdx.x == 0) { *st.arrive = 0u; *st.n_stale = 0u; *st.r_pending = 0u; *st.n_items = 0u; *st.pack_used = 0u; }
+    if (threadIdx.x == 0) { *st.items_total += *st.n_items; *st.arrive = 0u; *st.n_stale = 0u; *st.r_pending = 0u; *st.n_items = 0u; *st.pack_used = 0u; }
     if (threadIdx.x < 8) st.band_count[threadIdx.x] = 0u;
     // global arg-min, two passes over the linkages alone (coalesced, independent loads): the smallest value, then `better` among
     // the rows that hold it (its tie rule needs their ids; almost always a single row)
@@ -932,6 +935,15 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
         stamp();
         continue;
     }
+    if (st.no_seg) {
+        // a batch without segment launches (the host leaves them out while no merge needs them: a launch boundary costs ~4 us whatever
+        // the launch does): a long chain is walked whole right here -- exact as ever, slow, and counted, so that the host goes back to
+        // three launches for the next batch
+        const float acc = exact::ordered_walk<8>(chain_src(st, c), lane, 0, (uint64_t)c.cx * c.cy, 0.0f);
+        if (lane == 0) { finish_chain(st, c.s, c.dir, m, acc, fo); atomicAdd(st.whole_walks, 1u); }
+        stamp();
+        continue;
+    }
     uint32_t base = 0;
     if (lane == 0) { base = atomicAdd(st.n_items, c.nseg); st.item_start[w] = base; st.seg_done[w] = 0u; }
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -1234,7 +1246,7 @@ __global__ void upgma_init_kernel(UpgmaState st)
         *st.n_big = 0;
         *st.n_stale = st.n; *st.arrive = 0; *st.r_pending = 0; *st.n_items = 0; *st.pack_used = 0; *st.last_sq = 0;
         for (int b = 0; b < 8; ++b) st.band_count[b] = 0;
-        *st.n_ops = 0; *st.work = 0;
+        *st.n_ops = 0; *st.work = 0; *st.items_total = 0; *st.whole_walks = 0;
         *st.pool_used = st.n;
         *st.last_sp = 0xFFFFFFFFu;
         st.rec[0] = 0xFFFFFFFFu;
@@ -1329,6 +1341,7 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     st.pool_used = st.n_live + 12; st.last_sp = st.n_live + 4; st.last_sq = st.n_live + 5; st.n_items = st.n_live + 6;
     st.pack_used = st.n_live + 7; st.n_stale = st.n_live + 8; st.arrive = st.n_live + 9; st.r_pending = st.n_live + 10;
     st.n_big = st.n_live + 11; st.band_count = st.n_live + 16; st.rec = st.n_live + 24;   // (words 24..31: 32-byte aligned)
+    st.items_total = st.n_live + 13; st.whole_walks = st.n_live + 14;
     float *spare = nullptr;                                               // two more n x n buffers: the defragmented copies rotate through d_T and these
     auto fail = [&](int rc) { hipFree(pool); if (spare) hipFree(spare); if (st.dbg) hipFree(st.dbg); return rc; };
     if (distances_on_device) st.d = distances;
@@ -1386,7 +1399,7 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
         h_mat[2] = h_mat[0];                                              // "defragmented": any non-null word
         return hipMemcpyAsync((void *)d_mat, h_mat, sizeof(h_mat), hipMemcpyHostToDevice, ctx->stream);
     };
-    uint32_t host_state[4] = {n, 0, 0, 0};                                // n_live, n_ops, done, work
+    uint32_t host_state[16] = {n, 0, 0, 0};                               // n_live, n_ops, done, work; [13] segments made, [14] long chains walked whole
     // The merge loop is launch-bound (three short dependent launches per merge): a batch of merges is captured once into a
     // hipGraph and replayed until the device-side `done` flag rises; kernels launched after that return immediately.
     const uint32_t batch = 64;
@@ -1404,16 +1417,23 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     const bool debug_timing = std::getenv("APD_DEBUG_UPGMA_TIMING") != nullptr;   // tuning aid: phase stamps of every select launch
     if (debug_timing && hipMalloc((void **)&st.dbg, (size_t)n * 16 * sizeof(unsigned long long)) == hipSuccess)
         (void)hipMemsetAsync(st.dbg, 0, (size_t)n * 16 * sizeof(unsigned long long), ctx->stream);
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    auto enqueue_batch = [&]() {
+    // Two captured batches: [select, chain, segment] x 64 and [select, chain] x 64.  The second one is replayed while the batch before
+    // made no segment at all (most of a dendrogram at n = 4096: the segment launch then only costs its boundary, ~4.5 us per merge);
+    // its chain launch walks a long chain whole if one turns up after all, and the host returns to three launches for the next batch.
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipGraphExec_t exec[2] = {nullptr, nullptr};
+    auto enqueue_batch = [&](int two) {
+        UpgmaState sb = st;
+        sb.no_seg = two ? 1u : 0u;
         for (uint32_t b = 0; b < batch; ++b) {
-            hipLaunchKernelGGL(upgma_select_kernel, dim3(select_blocks), dim3(1024), 0, ctx->stream, st);
-            hipLaunchKernelGGL(upgma_chain_kernel, dim3(chain_blocks), dim3(256), 0, ctx->stream, st);
-            hipLaunchKernelGGL(upgma_segment_kernel, dim3(segment_blocks), dim3(256), 0, ctx->stream, st);
+            hipLaunchKernelGGL(upgma_select_kernel, dim3(select_blocks), dim3(1024), 0, ctx->stream, sb);
+            hipLaunchKernelGGL(upgma_chain_kernel, dim3(chain_blocks), dim3(256), 0, ctx->stream, sb);
+            if (!two) hipLaunchKernelGGL(upgma_segment_kernel, dim3(segment_blocks), dim3(256), 0, ctx->stream, sb);
         }
     };
-    auto drop_graph = [&]() { if (exec) hipGraphExecDestroy(exec); if (graph) hipGraphDestroy(graph); exec = nullptr; graph = nullptr; };
+    auto drop_graph = [&]() {
+        for (int g = 0; g < 2; ++g) { if (exec[g]) hipGraphExecDestroy(exec[g]); if (graph[g]) hipGraphDestroy(graph[g]); exec[g] = nullptr; graph[g] = nullptr; }
+    };
     e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return fail(APD_ERR_HIP); }
     // the legacy default stream cannot be captured: then the batch is enqueued directly
@@ -1423,17 +1443,27 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     bool use_graph = ctx->stream != nullptr && std::getenv("APD_UPGMA_NO_GRAPH") == nullptr &&   // (the env: plain launches, for profilers that choke on graphs)
                      hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
     if (use_graph) {
-        enqueue_batch();
-        use_graph = hipStreamEndCapture(ctx->stream, &graph) == hipSuccess && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        enqueue_batch(0);
+        use_graph = hipStreamEndCapture(ctx->stream, &graph[0]) == hipSuccess && hipGraphInstantiate(&exec[0], graph[0], nullptr, nullptr, 0) == hipSuccess;
+        if (use_graph && hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            enqueue_batch(1);
+            use_graph = hipStreamEndCapture(ctx->stream, &graph[1]) == hipSuccess && hipGraphInstantiate(&exec[1], graph[1], nullptr, nullptr, 0) == hipSuccess;
+        } else use_graph = false;
         if (!use_graph) drop_graph();
     }
     (void)hipGetLastError();
+    // APD_UPGMA_TWO_LAUNCH: 0 = always three launches per merge, 2 = always two (tests: every long chain walked whole), default = by batch
+    int two_policy = 1;
+    if (const char *v = std::getenv("APD_UPGMA_TWO_LAUNCH")) two_policy = std::atoi(v);
+    int two = two_policy == 2 ? 1 : 0;
+    uint32_t items_before = 0, whole_before = 0, n_two = 0, n_batches = 0;
     const bool debug = std::getenv("APD_DEBUG_UPGMA") != nullptr;
 
     uint32_t ops_before = 0;
     while (true) {
-        if (use_graph) e = hipGraphLaunch(exec, ctx->stream);
-        else { enqueue_batch(); e = hipGetLastError(); }
+        if (use_graph) e = hipGraphLaunch(exec[two], ctx->stream);
+        else { enqueue_batch(two); e = hipGetLastError(); }
+        ++n_batches; n_two += (uint32_t)two;
         if (e == hipSuccess) e = hipMemcpyAsync(host_state, st.n_live, sizeof(host_state), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); drop_graph(); return fail(APD_ERR_HIP); }
@@ -1446,6 +1476,11 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
             return fail(APD_ERR_HIP);
         }
         ops_before = host_state[1];
+        if (two_policy == 1) {
+            if (!two) two = host_state[13] == items_before ? 1 : 0;      // a whole batch without a segment: leave the segment launches out
+            else if (host_state[14] != whole_before) two = 0;            // a long chain turned up: three launches again
+        }
+        items_before = host_state[13]; whole_before = host_state[14];
         if (defrag_period && host_state[0] > 2 && host_state[1] - defrag_at >= defrag_period &&
             (defrag_forced || (uint64_t)(host_state[3] - defrag_work) >= 8ull * n)) {
             e = defragment();
@@ -1455,7 +1490,8 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
         }
     }
     drop_graph();
-    if (debug || debug_timing) std::fprintf(stderr, "[apd] upgma: %u defragmentations (period %u merges)\n", n_defrag, defrag_period);
+    if (debug || debug_timing) std::fprintf(stderr, "[apd] upgma: %u defragmentations (period %u merges); %u of %u batches without segment launches, %u long chains walked whole\n",
+                                            n_defrag, defrag_period, n_two, n_batches, host_state[14]);
     const uint32_t cnt = host_state[1];
     if (st.dbg) {
         std::vector<unsigned long long> g((size_t)n * 16);

@@ -233,3 +233,33 @@ def test_exact_sums_survive_extreme_value_ranges(ctx, oracle, kind):
     assert sorted(roots) == want_roots
     assert len(ops) > 100
 
+
+
+@pytest.mark.parametrize("n,kind,perc", [(64, "ties", 0.6), (300, "points", 0.05), (700, "nan", 0.5), (1100, "inf", 0.9), (1500, "big", 0.9),
+                                         (2048, "points", 0.05), (4096, "points", 0.05), (3000, "big", 0.3)])
+def test_batches_with_and_without_segment_launches_agree_bitwise(ctx, n, kind, perc, monkeypatch):
+    """The merge loop replays one of two captured batches: [select, chain, segment] x 64, or -- while the batch before made no
+    segment -- [select, chain] x 64, whose chain launch walks a long chain whole if one turns up after all (exact, slow, and the host
+    returns to three launches).  The default policy is held to the oracle's bits by the other tests of this file; here the same
+    matrices run with the policy pinned to "always three" (APD_UPGMA_TWO_LAUNCH=0) and "always two" (=2: EVERY long chain, up to 10^5
+    terms in the "big" matrices, is walked whole by one wavefront) and with the default: op records (ids, kinds, linkage bits), roots and
+    threshold must be identical (clustering.rs:153-187 has one answer)."""
+    from audio_pattern_discovery_amd.clustering import AgglomerativeClustering
+    d = synth.make_distance_matrix(n, kind, seed=n + len(kind))
+    results = []
+    for policy in ("0", "2", None):
+        if policy is None:
+            monkeypatch.delenv("APD_UPGMA_TWO_LAUNCH", raising=False)
+        else:
+            monkeypatch.setenv("APD_UPGMA_TWO_LAUNCH", policy)
+        ops, roots, thr = AgglomerativeClustering.clustering(d, n, perc, ctx, return_threshold=True)
+        rec = np.array([(o.merge_i, o.merge_j, o.into, int(o.operation), int(np.float32(o.distance).view(np.uint32))) for o in ops],
+                       dtype=np.int64).reshape(-1, 5)
+        results.append((rec, sorted(roots), np.float32(thr).view(np.uint32)))
+    base = results[0]
+    assert len(base[0]) > 0
+    for other in results[1:]:
+        assert other[0].shape == base[0].shape
+        bad = np.nonzero((other[0] != base[0]).any(axis=1))[0]
+        assert bad.size == 0, "first differing merge %d: %s vs %s" % (bad[0], other[0][bad[0]], base[0][bad[0]])
+        assert other[1] == base[1] and other[2] == base[2]
