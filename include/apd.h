@@ -304,7 +304,12 @@ int apd_percentile(apd_context *ctx, const float *x, uint64_t len, float perc, i
 
 /* ---- AgglomerativeClustering::clustering (src/clustering.rs:81-110) ------------------- */
 /* distances: n*n host (or device if distances_on_device).  ops capacity >= n, roots capacity >= n.
- * roots = dendrogram.clusters() in ascending id order (the reference returns a HashSet). */
+ * roots = dendrogram.clusters() in ascending id order (the reference returns a HashSet).
+ * Workspace: about 6 n^2 floats of device memory for the duration of the call (cluster sums, row-sum predictions, the two working
+ * copies of the matrix and the buffers they are re-laid out into, member lists); APD_ERR_OOM if it does not fit.
+ * Environment (tests / measurement only; results are bit-identical whatever they say): APD_UPGMA_TWO_LAUNCH=0|2 (always / never
+ * replay the segment launches), APD_UPGMA_DEFRAG=<merges> (least number of merges between two re-layouts, 0 = never),
+ * APD_UPGMA_NO_GRAPH=1 (plain launches instead of graph replay, for profilers), APD_DEBUG_UPGMA_TIMING=1 (phase stamps on stderr). */
 int apd_clustering(apd_context *ctx, const float *distances, int distances_on_device, uint32_t n,
                    float perc, apd_cluster_op *ops, uint32_t *n_ops, uint32_t *roots, uint32_t *n_roots,
                    float *threshold);
