@@ -329,12 +329,17 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
     __syncthreads();
     float lmin = __builtin_inff();
     constexpr uint32_t kAhead = 8;                                        // loads in flight per thread
-    for (uint32_t c0 = threadIdx.x; c0 < n; c0 += kAhead * blockDim.x) {
+    float v0[kAhead];                                                     // the first 8192 rows' linkages stay in the registers for the second pass
+#pragma unroll
+    for (uint32_t u = 0; u < kAhead; ++u) v0[u] = st.rb_l[min(threadIdx.x + u * blockDim.x, n - 1)];   // a clamped repeat changes no minimum
+#pragma unroll
+    for (uint32_t u = 0; u < kAhead; ++u) lmin = __builtin_fminf(lmin, v0[u]);                  // NaN never wins (fminf drops it)
+    for (uint32_t c0 = threadIdx.x + kAhead * blockDim.x; c0 < n; c0 += kAhead * blockDim.x) {
         float v[kAhead];
 #pragma unroll
-        for (uint32_t u = 0; u < kAhead; ++u) v[u] = st.rb_l[min(c0 + u * blockDim.x, n - 1)];   // a clamped repeat changes no minimum
+        for (uint32_t u = 0; u < kAhead; ++u) v[u] = st.rb_l[min(c0 + u * blockDim.x, n - 1)];
 #pragma unroll
-        for (uint32_t u = 0; u < kAhead; ++u) lmin = __builtin_fminf(lmin, v[u]);               // NaN never wins (fminf drops it)
+        for (uint32_t u = 0; u < kAhead; ++u) lmin = __builtin_fminf(lmin, v[u]);
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) lmin = __builtin_fminf(lmin, __shfl_xor(lmin, o));
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
         for (uint32_t c0 = threadIdx.x; c0 < n; c0 += kAhead * blockDim.x) {
             float v[kAhead];
 #pragma unroll
-            for (uint32_t u = 0; u < kAhead; ++u) v[u] = st.rb_l[min(c0 + u * blockDim.x, n - 1)];   // second pass: L2 hits
+            for (uint32_t u = 0; u < kAhead; ++u) v[u] = c0 == threadIdx.x ? v0[u] : st.rb_l[min(c0 + u * blockDim.x, n - 1)];   // second pass: registers, then L2 hits
 #pragma unroll
             for (uint32_t u = 0; u < kAhead; ++u) {
                 const uint32_t c = c0 + u * blockDim.x;
@@ -396,6 +401,7 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
     const uint32_t msp = st.mstart[w.sp], msq = st.mstart[w.sq], cp = st.mcount[w.sp], cq = st.mcount[w.sq], used = *st.pool_used;
     const float zp = st.size[w.sp], zq = st.size[w.sq];
     const uint32_t at = st.pos[w.sq], tail = st.live[nl - 1];
+    const uint32_t nb0 = *st.n_big, bps = st.bpos[w.sp], bq = st.bpos[w.sq], last_big = st.big[max(nb0, 1u) - 1u], work0 = *st.work;
     // merge the two sorted member lists into a fresh one
     {
         const uint32_t *lp = st.pool + msp, *lq = st.pool + msq, *pp = st.ppool + msp, *pq = st.ppool + msq;
@@ -422,15 +428,16 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
         else op = APD_SEQUENCE2CLUSTER;
         st.ops[t] = apd_cluster_op{w.idp, w.idq, k, w.l, op};
         *st.n_ops = t + 1;
-        *st.work += cp + cq;
+        *st.work = work0 + cp + cq;
         st.size[w.sp] = zp + zq;
         st.size[w.sq] = 0.0f;                                             // dead: skipped by every scan
         st.rb_l[w.sq] = __builtin_inff();
         {   // the clusters of two or more members: sp joins (if new), sq leaves (if it was one)
-            uint32_t nb = *st.n_big;
-            const uint32_t bq = st.bpos[w.sq];
-            if (st.bpos[w.sp] == 0xFFFFFFFFu) { st.big[nb] = w.sp; st.bpos[w.sp] = nb; ++nb; }
-            if (bq != 0xFFFFFFFFu) { const uint32_t tb = st.big[nb - 1]; st.big[bq] = tb; st.bpos[tb] = bq; st.bpos[w.sq] = 0xFFFFFFFFu; --nb; }
+            // (operands loaded up front with the others: the list's last entry is the one read there unless sp has just been appended)
+            uint32_t nb = nb0;
+            const bool joins = bps == 0xFFFFFFFFu;
+            if (joins) { st.big[nb] = w.sp; st.bpos[w.sp] = nb; ++nb; }
+            if (bq != 0xFFFFFFFFu) { const uint32_t tb = joins ? w.sp : last_big; st.big[bq] = tb; st.bpos[tb] = bq; st.bpos[w.sq] = 0xFFFFFFFFu; --nb; }
             *st.n_big = nb;
         }
         st.id[w.sp] = k;
