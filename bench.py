@@ -460,8 +460,9 @@ def clustering_leg(ctx, d_out, n, perc=0.05):
     return {"seconds": dt, "merges": m, "roots": int(n_roots.value), "threshold": float(thr.value), "percentile": perc,
             "us_per_merge": dt / max(m, 1) * 1e6, "bytes_per_merge": total_bytes / max(m, 1),
             "achieved_GBs": total_bytes / dt / 1e9, "hbm_frac": total_bytes / dt / 1e9 / HBM_PEAK_GBS,
-            "note": "apd_clustering on the resident matrix: radix-select threshold (4 passes over n^2 floats, included in `seconds`) + UPGMA, three "
-                    "launches per merge; latency-bound (dependent gathers and one serial tail per merge), not bandwidth-bound: see DESIGN.md section 4.3"}
+            "note": "apd_clustering on the resident matrix: radix-select threshold (4 passes over n^2 floats, included in `seconds`) + UPGMA, two or three "
+                    "launches per merge (the segment launches are left out of the replayed graph while no merge needs them); bound by launch boundaries "
+                    "and dependent gathers, not by bandwidth: see DESIGN.md section 4.3"}
 
 
 # ------------------------------------------------------------------------------------------------- launch modes
