@@ -99,6 +99,8 @@ SYMBOLS = [
     ("apd_all_gather_async", C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64]),
     ("apd_align_all_multi", C.c_int, [C.POINTER(C.c_int), C.c_uint32, _f32p, _u64p, C.c_uint32, C.c_uint32,
                                       C.POINTER(AlignConfig), _f32p, _u32p]),
+    ("apd_dtw_all_pairs", C.c_int, [_f32p, _u64p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _f32p]),
+    ("apd_upgma", C.c_int, [_f32p, C.c_uint32, C.c_float, C.POINTER(ClusterOp), _u32p, _u32p, _u32p]),
     ("apd_multi_create", C.c_int, [C.POINTER(C.c_int), C.c_uint32, C.POINTER(_vp)]),
     ("apd_multi_destroy", C.c_int, [_vp]),
     ("apd_multi_size", C.c_uint32, [_vp]),

@@ -552,6 +552,31 @@ extern "C" int apd_multi_synchronize(apd_multi *m) { APD_GUARDED(apd_multi_synch
 extern "C" int apd_multi_align_all(apd_multi *m, const apd_multi_batch *mb, const apd_align_config *cfg, float *out) { APD_GUARDED(apd_multi_align_all_impl(m, mb, cfg, out)) }
 extern "C" int apd_align_all_multi(const int *devices, uint32_t n_devices, const float *frames, const uint64_t *offsets, uint32_t n_seq, uint32_t dim, const apd_align_config *cfg, float *out, uint32_t *ranks_seen) { APD_GUARDED(apd_align_all_multi_impl(devices, n_devices, frames, offsets, n_seq, dim, cfg, out, ranks_seen)) }
 
+// ---- SURVEY.md section 8(b)'s one-call forms (alignments.rs:17-67 + main.rs:187-195; clustering.rs:81-110)
+static int apd_dtw_all_pairs_impl(const float *frames, const uint64_t *offsets, uint32_t n_seq, uint32_t dim, float band_pct, float ins_pen,
+                                  float del_pen, float match_pen, int n_devices, float *out)
+{
+    std::vector<int> devices((size_t)std::max(n_devices, 1));
+    for (size_t i = 0; i < devices.size(); ++i) devices[i] = (int)i;
+    const apd_align_config cfg{band_pct, ins_pen, del_pen, match_pen};
+    return apd_align_all_multi_impl(devices.data(), (uint32_t)devices.size(), frames, offsets, n_seq, dim, &cfg, out, nullptr);
+}
+extern "C" int apd_dtw_all_pairs(const float *frames, const uint64_t *offsets, uint32_t n_seq, uint32_t dim, float band_pct, float ins_pen,
+                                 float del_pen, float match_pen, int n_devices, float *out)
+{ APD_GUARDED(apd_dtw_all_pairs_impl(frames, offsets, n_seq, dim, band_pct, ins_pen, del_pen, match_pen, n_devices, out)) }
+
+static int apd_upgma_impl(const float *dist, uint32_t n, float perc, apd_cluster_op *ops, uint32_t *n_ops, uint32_t *roots, uint32_t *n_roots)
+{
+    apd_context *ctx = nullptr;
+    int rc = apd_create(0, &ctx);
+    if (rc != APD_OK) return rc;
+    rc = apd_clustering(ctx, dist, 0, n, perc, ops, n_ops, roots, n_roots, nullptr);
+    apd_destroy(ctx);
+    return rc;
+}
+extern "C" int apd_upgma(const float *dist, uint32_t n, float perc, apd_cluster_op *ops, uint32_t *n_ops, uint32_t *roots, uint32_t *n_roots)
+{ APD_GUARDED(apd_upgma_impl(dist, n, perc, ops, n_ops, roots, n_roots)) }
+
 // ------------------------------------------------------------------------------------------------------ runtime identity
 extern "C" uint64_t apd_runtime_info(char *out, uint64_t capacity)
 {

@@ -120,6 +120,9 @@ extern "C" {
     // several GPUs, one process: one-shot and persistent handle
     pub fn apd_align_all_multi(devices: *const c_int, n_devices: u32, frames: *const f32, offsets: *const u64, n_seq: u32, dim: u32,
                                cfg: *const apd_align_config, out: *mut f32, ranks_seen: *mut u32) -> c_int;
+    pub fn apd_dtw_all_pairs(frames: *const f32, offsets: *const u64, n_seq: u32, dim: u32, band_pct: f32, ins_pen: f32, del_pen: f32,
+                             match_pen: f32, n_devices: c_int, out: *mut f32) -> c_int;
+    pub fn apd_upgma(dist: *const f32, n: u32, perc: f32, ops: *mut apd_cluster_op, n_ops: *mut u32, roots: *mut u32, n_roots: *mut u32) -> c_int;
     pub fn apd_multi_create(devices: *const c_int, n_devices: u32, multi: *mut *mut apd_multi) -> c_int;
     pub fn apd_multi_destroy(multi: *mut apd_multi) -> c_int;
     pub fn apd_multi_size(multi: *const apd_multi) -> u32;

@@ -225,6 +225,18 @@ int apd_all_gather_async(apd_context *ctx, apd_comm *comm, const float *d_send, 
 int apd_align_all_multi(const int *devices, uint32_t n_devices, const float *frames, const uint64_t *offsets, uint32_t n_seq,
                         uint32_t dim, const apd_align_config *cfg, float *out, uint32_t *ranks_seen);
 
+/* The two one-call entry points SURVEY.md section 8(b) spells out for the Rust shim and the C++ harness -- the whole alignment leg
+ * (AlignmentWorkers::new + align_all, src/alignments.rs:17-67, main.rs:187-195) and the whole clustering leg
+ * (AgglomerativeClustering::clustering, src/clustering.rs:81-110) with host buffers in and out, the library owning contexts,
+ * device buffers and communicators for the duration of the call.  Synchronous, thread-compatible, 0 = OK, nothing unwinds.
+ * apd_dtw_all_pairs: frames [sum len][dim], offsets [n_seq + 1] in frames, out [n_seq][n_seq] caller-owned; devices 0 ..
+ *   n_devices - 1 (n_devices <= 1: device 0 alone); default distance mode.  = apd_align_all_multi over those devices.
+ * apd_upgma: dist [n][n] host, ops capacity >= n, roots capacity >= n; on device 0.  = apd_create + apd_clustering + apd_destroy.
+ * A host that calls them more than once keeps an apd_multi / apd_context instead and saves the set-up. */
+int apd_dtw_all_pairs(const float *frames, const uint64_t *offsets, uint32_t n_seq, uint32_t dim, float band_pct,
+                      float ins_pen, float del_pen, float match_pen, int n_devices, float *out);
+int apd_upgma(const float *dist, uint32_t n, float perc, apd_cluster_op *ops, uint32_t *n_ops, uint32_t *roots, uint32_t *n_roots);
+
 /* ---- (2) as a persistent handle: AlignmentWorkers { data, result } (alignments.rs:11-14) over n_devices GPUs ---------
  * apd_multi owns, for its whole life: one apd_context per device (own stream), the RCCL communicators of
  * ncclCommInitAll, one host worker thread per device (the reference's `alignment_workers` threads, alignments.rs:35-41:
