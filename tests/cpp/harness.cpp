@@ -62,6 +62,23 @@ int main(int argc, char **argv)
                         std::strncmp(workers.collective(), "rccl", 4) == 0 ? "rccl" : workers.collective());
         }
         auto res = apd::AgglomerativeClustering::clustering(ctx, workers.result, n, cfg.clustering_percentile);
+        {   // SURVEY.md section 8(b)'s two one-call entry points, straight through the C ABI: same bits as the mirror's calls
+            std::vector<float> flat;
+            std::vector<uint64_t> off(1, 0);
+            for (const auto &s : seqs) { flat.insert(flat.end(), s.frames.begin(), s.frames.end()); off.push_back(off.back() + s.len()); }
+            std::vector<float> out(n * n, -1.0f);
+            const int rc1 = apd_dtw_all_pairs(flat.data(), off.data(), (uint32_t)n, (uint32_t)seqs[0].n_bins, cfg.warping_band_percentage,
+                                              cfg.insertion_penalty, cfg.deletion_penalty, cfg.match_penalty, 1, out.data());
+            std::vector<apd_cluster_op> ops(n);
+            std::vector<uint32_t> roots(n);
+            uint32_t n_ops = 0, n_roots = 0;
+            const int rc2 = apd_upgma(workers.result.data(), (uint32_t)n, cfg.clustering_percentile, ops.data(), &n_ops, roots.data(), &n_roots);
+            bool same_ops = rc2 == 0 && n_ops == res.first.size() && n_roots == res.second.size();
+            for (uint32_t t = 0; same_ops && t < n_ops; ++t)
+                same_ops = ops[t].merge_i == res.first[t].merge_i && ops[t].merge_j == res.first[t].merge_j && ops[t].into == res.first[t].into &&
+                           std::memcmp(&ops[t].distance, &res.first[t].distance, sizeof(float)) == 0;
+            std::printf("onecall %d %d\n", (int)(rc1 == 0 && std::memcmp(out.data(), workers.result.data(), out.size() * sizeof(float)) == 0), (int)same_ops);
+        }
         for (const auto &o : res.first) std::printf("op %zu %zu %zu %.9g %d\n", o.merge_i, o.merge_j, o.into, o.distance, (int)o.operation);
         std::printf("roots");
         for (auto r : res.second) std::printf(" %zu", r);

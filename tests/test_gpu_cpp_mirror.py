@@ -39,6 +39,7 @@ def test_cpp_mirror_end_to_end(oracle, tmp_path):
     assert abs(pair - want[0, 1]) <= 1e-4 * want[0, 1]
     assert [l for l in lines if l.startswith("multi ")][0].split()[1:] == ["1", "1"]     # the multi-device handle on {0}: one rank, same bits
     assert [l for l in lines if l.startswith("multi_again")][0].split()[1:] == ["1", "rccl"]   # kept handle, second call, RCCL collective
+    assert [l for l in lines if l.startswith("onecall")][0].split()[1:] == ["1", "1"]     # apd_dtw_all_pairs / apd_upgma: same bits
 
 
 def test_cpp_mirror_with_the_references_on_disk_artefacts(oracle, tmp_path):
