@@ -207,7 +207,6 @@ struct UpgmaState {
     uint32_t *band_count;
     uint32_t band_cap;
     uint32_t short_chain;     // chains up to this many elements are walked whole by one wavefront
-    uint32_t ablate;          // timing-only experiments (results wrong): 1 no commit, 2 no segment maps, 4 no segment work at all, 8 no predict; 16 = round-robin XCD lists (results right)
     uint32_t *seg_done;       // [2 n] finished segments of a segmented chain
     float *packed;            // contiguous copies of the segments the commit pass is likely to re-walk (nullptr: off)
     uint32_t *pack_used;      // bump allocator of `packed`, reset per merge
@@ -957,14 +956,12 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
     // Every segment goes onto the work list of ONE XCD (blocks b and b + 8 of launch 3 share an XCD), chosen by where in the source
     // matrix it reads: a dir-0 chain reads the rows of d that belong to the new cluster -- band = (first row of the segment) * 8 /
     // |Ck|; a dir-1 chain reads those rows of the transposed copy at the columns of its own members -- band = (first column) * 8 / n.
-    // A locality hint only, any assignment is correct -- and a measured non-effect (round 4, same box, APD_UPGMA_ABLATE=16 deals the
-    // items round robin instead: chain proxy 5.68 vs 5.61 s, 16384-blob 0.892 vs 0.908 s): the gathers are not what launch 3 waits for.
-    if (st.ablate & 8u) continue;
+    // A locality hint only, any assignment is correct -- and a measured non-effect (round 4, same box, items dealt round robin
+    // instead: chain proxy 5.68 vs 5.61 s, 16384-blob 0.892 vs 0.908 s): the gathers are not what launch 3 waits for.
     for (uint32_t j = lane; j < c.nseg; j += 64) {
         st.item_chain[base + j] = w;
         const uint32_t a0 = j * c.rps;
         uint32_t band = c.dir == 0u ? (uint32_t)(((uint64_t)a0 * 8u) / c.cx) : (uint32_t)(((uint64_t)c.plx[a0] * 8u) / st.n);
-        if (st.ablate & 16u) band = (base + j) & 7u;                     // A/B: round robin (results stay right)
         st.band_items[(uint64_t)min(band, 7u) * st.band_cap + atomicAdd(&st.band_count[min(band, 7u)], 1u)] = base + j;
     }
     predict_chain(st, c, sp, m.sq, lane, st.seg + base);
@@ -1084,7 +1081,6 @@ __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
     const uint32_t *list = st.band_items + (uint64_t)xcd * st.band_cap;
     for (uint32_t k = v; k < mine; k += waves_per_xcd) {
         const uint32_t item = list[k];
-        if (st.ablate & 4u) continue;
         const uint32_t w = st.item_chain[item];
         const Chain c = get_chain(st, w, m);
         const exact::GatherSrc src = chain_src(st, c);
@@ -1100,7 +1096,7 @@ __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
             const uint64_t end0 = min<uint64_t>((uint64_t)c.rps * c.cy, (uint64_t)c.cx * c.cy);
             exact_bits = __builtin_bit_cast(uint32_t, exact::ordered_walk<8>(src, lane, 0, end0, 0.0f));
             es_out = kExactSegment;
-        } else if (es >= 1u && es <= 254u && !(st.ablate & 2u)) {
+        } else if (es >= 1u && es <= 254u) {
             const uint64_t begin = (uint64_t)j * c.rps * c.cy, end = min<uint64_t>(begin + (uint64_t)c.rps * c.cy, (uint64_t)c.cx * c.cy);
             const uint32_t len = (uint32_t)(end - begin);
             // will the commit re-walk this segment?  (the next segment's prediction is this segment's predicted end)
@@ -1129,7 +1125,7 @@ __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // (a wait for this wavefront's stores; no cache write-back)
         if (lane == 0) finished = atomicAdd(&st.seg_done[w], 1u) + 1u;   // ... then the count
         finished = (uint32_t)__builtin_amdgcn_readfirstlane((int)finished);
-        if (finished == c.nseg && !(st.ablate & 1u)) {
+        if (finished == c.nseg) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             const unsigned long long t0 = st.dbg ? wall_clock64() : 0ull;
             uint32_t rw = 0;
@@ -1446,7 +1442,6 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     // the legacy default stream cannot be captured: then the batch is enqueued directly
     st.short_chain = kShortChain;
     if (const char *v = std::getenv("APD_UPGMA_SHORT_CHAIN")) st.short_chain = (uint32_t)std::max(64, std::atoi(v));   // tuning
-    if (const char *v = std::getenv("APD_UPGMA_ABLATE")) st.ablate = (uint32_t)std::atoi(v);   // timing-only: results become wrong
     bool use_graph = ctx->stream != nullptr && std::getenv("APD_UPGMA_NO_GRAPH") == nullptr &&   // (the env: plain launches, for profilers that choke on graphs)
                      hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
     if (use_graph) {
