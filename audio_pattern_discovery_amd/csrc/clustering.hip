@@ -8,15 +8,19 @@
 //   are recomputed from the raw distances in EXACTLY the reference's order (x ascending over Cp, y ascending over Cq,
 //   one running f32 accumulator, clustering.rs:157-169) from sorted member lists, so every linkage -- and with it the
 //   whole merge sequence, including the p/q order of mathematically tied directed pairs that the reference settles
-//   by rounding noise -- is bit-identical to the literal algorithm.  Each merge is THREE launches (round 3: eight):
+//   by rounding noise -- is bit-identical to the literal algorithm.  Each merge is THREE launches (round 3: eight), TWO while no
+//   merge needs the third (a second captured batch without it, see apd_clustering):
 //     upgma_select_kernel   row minima of the rows whose cached best pair went stale (a compact list), then -- in the
-//                           workgroup that finishes last -- the global arg-min, merge_clusters, the merged member list;
+//                           workgroup that finishes last -- the global arg-min, merge_clusters, the merged member list, and
+//                           one 32-byte record of the merge for the other two launches;
 //     upgma_chain_kernel    every chain of the new cluster's row and column of S that one lane or one wavefront sums
 //                           whole; long chains get their segments allocated (atomic bump) and predicted here;
 //     upgma_segment_kernel  the segments' integer maps, and -- in the wavefront that finishes a chain's last segment --
 //                           the in-order commit of that chain.
 //   No workgroup ever waits for another one: "last to arrive does the serial part" (an atomic counter and a fence), so the
-//   kernels cannot deadlock whatever the scheduler does.  Exact ties resolve to the lowest (id_p, id_q): what the
+//   kernels cannot deadlock whatever the scheduler does.  Between two replays of a batch the host may have the working copies
+//   of d re-laid out so that a cluster's members are neighbouring rows and columns (upgma_permute_kernel): which elements are
+//   added, and in which order, never changes -- only where they lie.  Exact ties resolve to the lowest (id_p, id_q): what the
 //   reference does when its HashSet happens to iterate in ascending order (clustering.rs:180-187); any other order is
 //   equally "reference".
 #include <algorithm>
