@@ -308,18 +308,24 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
         __syncthreads();
         if (threadIdx.x == 0) {
             const Cand found = kmin != ~0ull ? Cand{kwin_l, idp, (uint32_t)kmin, sp, kwin} : best;
-            st.rbest[sp] = found; st.rb_l[sp] = found.l; st.rscan[sp] = 0;
+            // (agent-scope stores: what the last workgroup to arrive reads of this one travels past this XCD's L2 by itself, see below)
+            Cand *o = st.rbest + sp;
+            store_agent(&o->l, found.l); store_agent(&o->idp, found.idp); store_agent(&o->idq, found.idq); store_agent(&o->sp, found.sp); store_agent(&o->sq, found.sq);
+            store_agent(&st.rb_l[sp], found.l); store_agent(&st.rscan[sp], 0u);
         }
     }
     // ---- who is last?  (the classic fence + counter: every workgroup's writes above are visible to the one that sees the full count)
     const unsigned long long t_rows = st.dbg ? wall_clock64() : 0ull;
-    // ONE agent-scope fence per workgroup, behind the barrier (on a multi-XCD part a release fence writes the XCD's L2 back: sixteen
-    // wavefronts doing it each was most of this launch's 34 us at n = 4096)
+    // What the last workgroup reads of the others -- the row minima -- was written by thread 0 with agent-scope stores, so arriving
+    // needs no agent-scope RELEASE fence (on a multi-XCD part that writes the XCD's L2 back: sixteen wavefronts doing it each was most
+    // of this launch's 34 us at n = 4096, one per workgroup still 1.5 us): thread 0 waits for its own stores, then counts itself in.
+    // Only the workgroup that finds itself last pays an acquire (its L1 / L2 may hold older copies of those lines).  The R updates
+    // above are plain stores: nothing in this launch reads them, the end of the launch publishes them.
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         is_last = atomicAdd(st.arrive, 1u) == gridDim.x - 1u ? 1u : 0u;
-        __threadfence();
+        if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
     if (is_last == 0u) return;
