@@ -204,7 +204,8 @@ struct UpgmaState {
     apd_cluster_op *ops;      // [n]
     uint32_t *n_ops;
     uint32_t *work;           // sum of the new clusters' member counts so far (wraps; the host looks at differences): when to defragment
-    float *R;                 // [n][n] R[x][slot]: approximate sum of d[x][y] over the members y of the cluster in `slot`
+    float *R;                 // [n][n] R[slot][x]: approximate sum of d[x][y] over the members y of the cluster in `slot` (a ROW per slot: a
+                              // merge adds one row to another, 2 n contiguous floats, where a column per slot cost n scattered cache lines)
     uint32_t *item_start;     // [2 n] first work item (segment) of a segmented chain of the current merge
     uint32_t *item_chain;     // [max_items] chain of every work item
     uint32_t *band_items;     // [8][max_items] the items of every XCD's band (see upgma_segment_kernel); band_count[8]
@@ -242,10 +243,9 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
     if (finished != 0u) return;
     if (pending != 0u) {
         // the R update is dealt from the far end of the grid: the stale rows start at workgroup 0
-        for (uint32_t x = (gridDim.x - 1u - blockIdx.x) * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
-            float *r = st.R + (uint64_t)x * n;
-            r[sp0] = r[sp0] + r[sq0];
-        }
+        float *rp = st.R + (uint64_t)sp0 * n;
+        const float *rq = st.R + (uint64_t)sq0 * n;
+        for (uint32_t x = (gridDim.x - 1u - blockIdx.x) * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) rp[x] = rp[x] + rq[x];
     }
     for (uint32_t r = blockIdx.x; r < ns; r += gridDim.x) {
         const uint32_t sp = r == blockIdx.x ? first_stale : st.stale[r];
@@ -848,8 +848,8 @@ __device__ void predict_chain(const UpgmaState &st, const Chain &c, uint32_t sp,
         const uint32_t a = a0 + lane;
         float v = 0.0f;
         if (a < c.cx) {
-            const float *r = st.R + (uint64_t)c.lx[a] * st.n;
-            v = fresh ? r[sp] + r[sq] : r[c.slot_y];
+            const uint32_t x = c.lx[a];
+            v = fresh ? st.R[(uint64_t)sp * st.n + x] + st.R[(uint64_t)sq * st.n + x] : st.R[(uint64_t)c.slot_y * st.n + x];
         }
         float incl = v;                                                  // inclusive scan over the lanes (any rounding will do)
 #pragma unroll
@@ -1160,7 +1160,6 @@ __global__ void upgma_init_S_kernel(UpgmaState st)
     {
         const float v = st.d[e];
         st.S[e] = 0.0f + v;                                               // distance = 0.0 + d[x][y] (:154,162)
-        st.R[e] = v;                                                      // singleton clusters: slot y holds instance y
     }
 }
 
@@ -1375,6 +1374,9 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     hipLaunchKernelGGL(upgma_init_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, st);
     hipLaunchKernelGGL(upgma_transpose_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)((n + 31) / 32) * ((n + 31) / 32), 16384)), dim3(256), 0,
                        ctx->stream, st.d, d_T, n);
+    // R[slot y][x] = d[x][y] while every cluster is a singleton (slot y holds instance y): the transpose
+    e = hipMemcpyAsync(st.R, d_T, bytes_S, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return fail(APD_ERR_HIP); }
     // the working copies start out as the caller's matrix and its transpose
     const float *h_mat[3] = {st.d, d_T, nullptr};
     e = hipMemcpyAsync((void *)d_mat, h_mat, sizeof(h_mat), hipMemcpyHostToDevice, ctx->stream);
