@@ -208,9 +208,6 @@ struct UpgmaState {
                               // merge adds one row to another, 2 n contiguous floats, where a column per slot cost n scattered cache lines)
     uint32_t *item_start;     // [2 n] first work item (segment) of a segmented chain of the current merge
     uint32_t *item_chain;     // [max_items] chain of every work item
-    uint32_t *band_items;     // [8][max_items] the items of every XCD's band (see upgma_segment_kernel); band_count[8]
-    uint32_t *band_count;
-    uint32_t band_cap;
     uint32_t short_chain;     // chains up to this many elements are walked whole by one wavefront
     uint32_t *seg_done;       // [2 n] finished segments of a segmented chain
     float *packed;            // contiguous copies of the segments the commit pass is likely to re-walk (nullptr: off)
@@ -331,7 +328,6 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaState st)
     if (is_last == 0u) return;
     const unsigned long long t_last = st.dbg ? wall_clock64() : 0ull;
     if (threadIdx.x == 0) { *st.items_total += *st.n_items; *st.arrive = 0u; *st.n_stale = 0u; *st.r_pending = 0u; *st.n_items = 0u; *st.pack_used = 0u; }
-    if (threadIdx.x < 8) st.band_count[threadIdx.x] = 0u;
     // global arg-min, two passes over the linkages alone (coalesced, independent loads): the smallest value, then `better` among
     // the rows that hold it (its tie rule needs their ids; almost always a single row)
     if (threadIdx.x == 0) { lmin_key = 0xFFFFFFFFu; kmin = ~0ull; win = Cand{__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0}; }
@@ -963,17 +959,10 @@ __global__ __launch_bounds__(256) void upgma_chain_kernel(UpgmaState st)
     uint32_t base = 0;
     if (lane == 0) { base = atomicAdd(st.n_items, c.nseg); st.item_start[w] = base; st.seg_done[w] = 0u; }
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    // Every segment goes onto the work list of ONE XCD (blocks b and b + 8 of launch 3 share an XCD), chosen by where in the source
-    // matrix it reads: a dir-0 chain reads the rows of d that belong to the new cluster -- band = (first row of the segment) * 8 /
-    // |Ck|; a dir-1 chain reads those rows of the transposed copy at the columns of its own members -- band = (first column) * 8 / n.
-    // A locality hint only, any assignment is correct -- and a measured non-effect (round 4, same box, items dealt round robin
-    // instead: chain proxy 5.68 vs 5.61 s, 16384-blob 0.892 vs 0.908 s): the gathers are not what launch 3 waits for.
-    for (uint32_t j = lane; j < c.nseg; j += 64) {
-        st.item_chain[base + j] = w;
-        const uint32_t a0 = j * c.rps;
-        uint32_t band = c.dir == 0u ? (uint32_t)(((uint64_t)a0 * 8u) / c.cx) : (uint32_t)(((uint64_t)c.plx[a0] * 8u) / st.n);
-        st.band_items[(uint64_t)min(band, 7u) * st.band_cap + atomicAdd(&st.band_count[min(band, 7u)], 1u)] = base + j;
-    }
+    // The chain's segments are items base .. base + nseg - 1; wavefront v of launch 3 takes item v.  (Until the end of round 4 every
+    // segment also went onto the work list of ONE XCD, chosen by where in the source matrix it reads -- a locality hint that measured
+    // as a non-effect against round-robin dealing and cost an atomic per segment on eight addresses, two thousand per merge.)
+    for (uint32_t j = lane; j < c.nseg; j += 64) st.item_chain[base + j] = w;
     predict_chain(st, c, sp, m.sq, lane, st.seg + base);
     stamp();
     }
@@ -1081,17 +1070,14 @@ __device__ void commit_chain(const UpgmaState &st, const Chain &c, const MergeRe
 __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
 {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t xcd = blockIdx.x & 7u, v = (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6);   // v-th wavefront of this XCD (blocks b and b + 8 share one)
-    const uint32_t waves_per_xcd = (gridDim.x >> 3) * 4u;                                      // gridDim.x is a multiple of 64
-    // one round trip: the item count (zero for most merges: this launch is then over), the XCD's share, the merge record
-    const uint32_t n_items = *st.n_items, mine = st.band_count[xcd];
+    const uint32_t v = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+    // one round trip: the item count (zero for most merges: this launch is then over), the merge record, this wavefront's item's chain
+    const uint32_t n_items = *st.n_items, w_first = st.item_chain[v];   // (item_chain holds max_items >= the grid's wavefronts entries)
     const MergeRec m = load_rec(st);
     const uint32_t sp = m.sp;
     if (sp == 0xFFFFFFFFu || n_items == 0u) return;
-    const uint32_t *list = st.band_items + (uint64_t)xcd * st.band_cap;
-    for (uint32_t k = v; k < mine; k += waves_per_xcd) {
-        const uint32_t item = list[k];
-        const uint32_t w = st.item_chain[item];
+    for (uint32_t item = v; item < n_items; item += n_waves) {
+        const uint32_t w = item == v ? w_first : st.item_chain[item];
         const Chain c = get_chain(st, w, m);
         const exact::GatherSrc src = chain_src(st, c);
         const uint32_t first = st.item_start[w], j = item - first;
@@ -1122,7 +1108,7 @@ __global__ __launch_bounds__(256) void upgma_segment_kernel(UpgmaState st)
             }
             maps = exact::segment_fn(src, lane, begin, end, es, pack_off != 0xFFFFFFFFu ? st.packed + pack_off : nullptr);
         }
-        if (st.dbg && lane == 0 && k == 0 && xcd == 0) st.dbg[(uint64_t)(m.t - 1u) * 16 + 10] = n_items;
+        if (st.dbg && lane == 0 && item == 0u) st.dbg[(uint64_t)(m.t - 1u) * 16 + 10] = n_items;
         uint32_t finished = 0;
         if (lane < 4) {                                                  // lane q publishes sub-block q's maps (uniform values: any lane holds them)
             uint32_t a0 = maps.f[0].a0, a1 = maps.f[0].a1, b0 = maps.g[0].a0, b1 = maps.g[0].a1;
@@ -1257,7 +1243,6 @@ __global__ void upgma_init_kernel(UpgmaState st)
         *st.n_live = st.n;
         *st.n_big = 0;
         *st.n_stale = st.n; *st.arrive = 0; *st.r_pending = 0; *st.n_items = 0; *st.pack_used = 0; *st.last_sq = 0;
-        for (int b = 0; b < 8; ++b) st.band_count[b] = 0;
         *st.n_ops = 0; *st.work = 0; *st.items_total = 0; *st.whole_walks = 0;
         *st.pool_used = st.n;
         *st.last_sp = 0xFFFFFFFFu;
@@ -1306,7 +1291,7 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     // segments of one merge: sum over chains of ceil(rows / rows-per-segment) <= 2 (sum of chain lengths) / kSegElems + chains,
     // and the chains of one merge hold 2 |Ck| (n - |Ck|) <= n^2 / 2 elements
     const size_t max_items = (size_t)(nn / kSegElems) + 2 * (size_t)n + 64;
-    const size_t bytes_items = (2 * (size_t)n + 2) * sizeof(uint32_t), bytes_seg = max_items * sizeof(SegRes), bytes_ichain = max_items * sizeof(uint32_t);
+    const size_t bytes_items = (2 * (size_t)n + 2) * sizeof(uint32_t), bytes_seg = max_items * sizeof(SegRes), bytes_ichain = std::max<size_t>(max_items, 4 * 8192 + 256) * sizeof(uint32_t)   /* (every wavefront of the segment grid reads its entry) */;
     // packed copies of the segments the commit pass is likely to re-walk (a few per chain); when it is full, they are gathered again
     const size_t bytes_packed = (size_t)std::min<uint64_t>(nn / 8 + 65536, 1ull << 30) * sizeof(float);
     // one allocation, every array on a 256-byte boundary (the row scans read S rows, sizes and ids with 16-byte loads)
@@ -1316,7 +1301,7 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
                  o_id = carve(bytes_u), o_live = carve(bytes_u), o_mstart = carve(bytes_u), o_mcount = carve(bytes_u), o_rscan = carve(bytes_u),
                  o_pos = carve(bytes_u), o_big = carve(bytes_u), o_bpos = carve(bytes_u), o_rbl = carve(bytes_f), o_stale = carve(bytes_u),
                  o_rbest = carve((size_t)n * sizeof(Cand)), o_ops = carve((size_t)n * sizeof(apd_cluster_op)), o_seg = carve(bytes_seg),
-                 o_istart = carve(bytes_items), o_sdone = carve(bytes_items), o_ichain = carve(bytes_ichain), o_band = carve(8 * bytes_ichain), o_packed = carve(bytes_packed),
+                 o_istart = carve(bytes_items), o_sdone = carve(bytes_items), o_ichain = carve(bytes_ichain), o_packed = carve(bytes_packed),
                  o_T = carve(bytes_S), o_phys = carve(bytes_u), o_dsrc = carve(bytes_u), o_doff = carve(bytes_u), o_words = carve(256);
     HIP_TRY(ctx, hipMalloc((void **)&pool, off));
     st.S = (float *)(pool + o_S);
@@ -1342,8 +1327,6 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     st.item_start = (uint32_t *)(pool + o_istart);
     st.seg_done = (uint32_t *)(pool + o_sdone);
     st.item_chain = (uint32_t *)(pool + o_ichain);
-    st.band_items = (uint32_t *)(pool + o_band);
-    st.band_cap = (uint32_t)max_items;
     st.packed = (float *)(pool + o_packed);
     st.pack_capacity = (uint32_t)(bytes_packed / sizeof(float));
     float *d_T = (float *)(pool + o_T);
@@ -1352,7 +1335,7 @@ extern "C" int apd_clustering(apd_context *ctx, const float *distances, int dist
     st.n_live = (uint32_t *)(pool + o_words); st.n_ops = st.n_live + 1; st.done = st.n_live + 2; st.work = st.n_live + 3;   // host_state reads these four
     st.pool_used = st.n_live + 12; st.last_sp = st.n_live + 4; st.last_sq = st.n_live + 5; st.n_items = st.n_live + 6;
     st.pack_used = st.n_live + 7; st.n_stale = st.n_live + 8; st.arrive = st.n_live + 9; st.r_pending = st.n_live + 10;
-    st.n_big = st.n_live + 11; st.band_count = st.n_live + 16; st.rec = st.n_live + 24;   // (words 24..31: 32-byte aligned)
+    st.n_big = st.n_live + 11; st.rec = st.n_live + 24;   // (words 24..31: 32-byte aligned)
     st.items_total = st.n_live + 13; st.whole_walks = st.n_live + 14;
     float *spare = nullptr;                                               // two more n x n buffers: the defragmented copies rotate through d_T and these
     auto fail = [&](int rc) { hipFree(pool); if (spare) hipFree(spare); if (st.dbg) hipFree(st.dbg); return rc; };
